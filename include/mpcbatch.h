@@ -1,0 +1,190 @@
+/*
+ * mpcbatch.h — C ABI of libmpcbatch: batched multiple-shooting MPC solves on AMD MI355X (gfx950).
+ *
+ * This library takes the place of ONE call in the reference (ZhuorenLi/MPC_motion_planning):
+ *
+ *     solver = ca.nlpsol('solver', 'ipopt', nlp_prob, opts)      CMOM/MPC_CBF_optimize_kin.py:251-254
+ *     res    = solver(x0=, p=, lbg=, lbx=, ubg=, ubx=)            CMOM/main_cbf_kin_c_sim.py:100
+ *
+ * (CMOM = CasaDi_MPC_Optimize_Multishoot/).  The reference has no FFI of its own — its solve lives in
+ * the third-party casadi wheel (IPOPT + MUMPS) — so the entry points below are what a ctypes binding
+ * placed at that seam needs: "describe the NLP once" (mpcb_create / mpcb_set_bounds) and "solve it for a
+ * batch of parameter vectors P = [x0; xs] and obstacle sets" (mpcb_solve).  INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain C, opaque handle, caller-owned buffers, every function returns an int code
+ *     (MPCB_OK = 0, < 0 = API error, text via mpcb_last_error).  Nothing aborts.
+ *   - all floating point is IEEE double, as in the reference (CasADi DM / numpy float64).
+ *   - batch arrays are row-major [B, ...] both on the host and on the device: one problem instance
+ *     is one contiguous row, which is the coalesced layout for "one wavefront per instance".
+ *   - decision vector order is the reference's:  z = [vec(U); vec(X)], z[2i+c] = U[c,i],
+ *     z[2N + nx*k + s] = X[s,k]                                  CMOM/MPC_CBF_optimize_kin.py:160-161,250
+ *   - constraint row order (g, lbg, ubg) is the reference's       CMOM/MPC_CBF_optimize_kin.py:107-132,190-247
+ *   - per-instance solver outcome goes to status[] (MPCB_ST_*), never to the return code.
+ *   - one handle = one device + one stream; calls on one handle must be serialised by the caller.
+ */
+#ifndef MPCBATCH_H
+#define MPCBATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPCB_ABI_VERSION 1
+
+/* return codes */
+#define MPCB_OK              0
+#define MPCB_E_INVALID      -1   /* bad argument / config */
+#define MPCB_E_BOUNDS       -2   /* lbx/ubx/lbg/ubg do not match the row pattern of the configured NLP */
+#define MPCB_E_DEVICE       -3   /* HIP runtime error (no GPU, out of memory, launch failure) */
+#define MPCB_E_UNSUPPORTED  -4   /* valid request that this build does not implement */
+
+/* per-instance status */
+#define MPCB_ST_SOLVED        0  /* scaled NLP error <= tol (IPOPT "Optimal Solution Found") */
+#define MPCB_ST_MAXITER       1  /* max_iter reached; last iterate returned (the reference ignores status too) */
+#define MPCB_ST_LINESEARCH    2  /* no acceptable step (where IPOPT would enter restoration) */
+#define MPCB_ST_INFEASIBLE_X0 3  /* x0 violates a state box or lies inside an obstacle row at node 0 */
+#define MPCB_ST_NUMERIC       4  /* regularisation exhausted or non-finite number */
+
+/* models                                                     reference */
+#define MPCB_MODEL_KIN 0      /* 4-state kinematic bicycle     CMOM/MPC_CBF_optimize_kin.py:153-156 */
+#define MPCB_MODEL_DYN 1      /* 6-state dynamic bicycle       CMOM/MPC_CBF_optimize_dyn.py:156-170 */
+
+/* obstacle rows */
+#define MPCB_OBS_KEEPOUT 0    /* h_j(X_i) >= 0, the shipped form          CMOM/MPC_CBF_optimize_kin.py:247 */
+#define MPCB_OBS_DCBF    1    /* gamma*h + (h_next - h) >= 0, commented   CMOM/MPC_CBF_optimize_kin.py:248 */
+
+/* barrier-parameter strategies */
+#define MPCB_MU_MONOTONE 0    /* IPOPT default: Fiacco-McCormick, mu_init = 0.1, kappa_mu = 0.2, theta_mu = 1.5 */
+#define MPCB_MU_ADAPTIVE 1    /* Mehrotra probing: sigma = (mu_aff/mu)^3 + second-order corrector (IPOPT mu_oracle = probing) */
+
+/* obstacle input kinds for mpcb_solve */
+#define MPCB_OBSIN_STATIC    0 /* [B, n_obs, 6]       rows [x,y,theta,v,l,w]   CMOM/main_cbf_kin_c_sim.py:55 */
+#define MPCB_OBSIN_PREDICTED 1 /* [B, n_obs, N+1, 6]  CMOM/Obs_prediction.py:33-38 (rows i<N are read) */
+
+#define MPCB_NX_MAX   6
+#define MPCB_NU       2
+#define MPCB_NOBS_MAX 8
+#define MPCB_N_MAX    63      /* N+1 nodes map onto the 64 lanes of one wavefront */
+
+typedef struct mpcb_config {
+  uint32_t struct_size;       /* = sizeof(mpcb_config); checked */
+  int32_t  model;             /* MPCB_MODEL_* */
+  int32_t  N;                 /* N_p, shooting intervals                  kin.py:32-33 */
+  int32_t  n_obs;             /* obstacle rows per node, 0..MPCB_NOBS_MAX */
+  int32_t  obs_mode;          /* MPCB_OBS_* */
+  int32_t  obs_terminal;      /* 0: rows at nodes 0..N-1 (kin.py:236); 1: nodes 0..N (dyn.py:242) */
+  int32_t  du0_cost;          /* 1: (U_0-Ulast)' DR (U_0-Ulast) in the cost (kin.py:203-204); 0: none (dyn.py:223-224) */
+  int32_t  rate_interleaved;  /* order of the rate rows inside g: 0 = one block after all dynamics rows (kin.py:211-216),
+                                 1 = after each stage's dynamics rows (dyn.py:226-231).  Affects lam_g / bounds order only. */
+  int32_t  max_iter;          /* ipopt.max_iter = 100                     kin.py:252 */
+  int32_t  mu_strategy;       /* MPCB_MU_* : barrier update rule */
+  int32_t  init_rollout;      /* 0: take the X part of the start as given (what IPOPT receives);
+                                 1: keep U of the start, roll X out from x0 with the model (multiple-shooting warm start) */
+  double   T;                 /* T_S */
+  double   gamma;             /* DCBF gamma (kin.py:235) */
+  double   Q[MPCB_NX_MAX];    /* diag of Q                                kin.py:168-172 */
+  double   R[MPCB_NU];        /* diag of R                                kin.py:179-181 */
+  double   DR[MPCB_NU];       /* diag of DR                               kin.py:182-184 */
+  double   u_last[MPCB_NU];   /* Ulast = [0,0]                            kin.py:193 */
+  double   u_lo[MPCB_NU], u_hi[MPCB_NU];       /* boxes on U (lbx)        kin.py:90-95 */
+  double   x_lo[MPCB_NX_MAX], x_hi[MPCB_NX_MAX]; /* boxes on X, +-inf = none  kin.py:97-105 */
+  double   du_lo[MPCB_NU], du_hi[MPCB_NU];     /* rows U[c,i]-U[c,i-1], i=1..N-1; +-inf = no row  kin.py:116-121,211-216 */
+  double   obs_hmin;          /* row is h >= obs_hmin: 0 (kin.py:129-132); 1 for the dyn sqrt(h)>=1 form (dyn.py:131-133,243) */
+  double   ego_hl, ego_hw;    /* Veh_L/2, Veh_W/2                         kin.py:220-221 */
+  double   safe_disl, safe_disw; /* 1.0, 0.5                              kin.py:224-225 */
+  double   obs_sx_fixed, obs_sy_fixed; /* > 0: fixed semi-axes (dyn.py:240-241: 4, 1); else from l,w */
+  double   veh_l;             /* wheelbase (kin)                          kin.py:155 */
+  double   veh_m, veh_lf, veh_lr, veh_Iz;      /* dyn                     dyn.py:165-170 */
+  double   Fymax_f, Fymax_r, aopt_f, aopt_r;   /* dyn tyre                dyn.py:158-159 */
+  /* interior-point options: IPOPT's documented defaults unless the reference sets them (kin.py:252-253) */
+  double   tol;               /* 1e-8 */
+  double   mu_init;           /* 0.1 */
+  double   bound_push;        /* 0.01 (kappa_1) */
+  double   bound_frac;        /* 0.01 (kappa_2) */
+  double   bound_relax;       /* 1e-8 (bound_relax_factor) */
+  double   max_gradient;      /* 100 (nlp_scaling_max_gradient) */
+} mpcb_config;
+
+typedef struct mpcb_handle mpcb_handle;
+
+/* Fill cfg with the shipped kinematic problem (weights kin.py:168-184, limits from mpc_parameters.yaml,
+ * IPOPT defaults) for horizon N and step T; model = MPCB_MODEL_KIN or MPCB_MODEL_DYN. */
+int mpcb_default_config(mpcb_config* cfg, int32_t model, int32_t N, double T);
+
+/* sizes implied by a config: nx, nz = 2N + nx(N+1), ng = rows of g in the reference's order */
+int mpcb_dims(const mpcb_config* cfg, int32_t* nx, int32_t* nz, int32_t* ng);
+
+int mpcb_device_count(void);
+
+/* Create a solver for one NLP structure on HIP device `device` (replaces ca.nlpsol(...), kin.py:254). */
+int mpcb_create(const mpcb_config* cfg, int32_t device, mpcb_handle** out);
+int mpcb_destroy(mpcb_handle* h);
+const char* mpcb_last_error(const mpcb_handle* h);   /* h may be NULL: last creation error */
+
+/* Check caller-supplied bounds (the lists initialize_constraints returns, kin.py:84-134) against the
+ * configured row pattern and adopt the numeric limits.  A length or pattern mismatch — e.g. the
+ * interleaving defect of MPC_CBF_optimize_dyn.py:112-129 vs :215-231 — is MPCB_E_BOUNDS. */
+int mpcb_set_bounds(mpcb_handle* h, const double* lbx, const double* ubx, int32_t nz,
+                    const double* lbg, const double* ubg, int32_t ng);
+
+/* Solve B independent instances (replaces `res = solver(x0=, p=, ...)`, main_cbf_kin_c_sim.py:100).
+ *   x0   [B, nx]   initial state  (P[0:nx])
+ *   xs   [B, nx]   set-point      (P[nx:2nx])
+ *   obs  [B, n_obs, 6] or [B, n_obs, N+1, 6] per obs_kind; may be NULL when n_obs == 0
+ *   z0   [B, nz]   primal start (solver(x0=...)); NULL = zeros (main_cbf_kin_c_sim.py:47-50)
+ * outputs (each may be NULL except z):
+ *   z [B, nz] = res['x'];  obj [B] = res['f'];  status [B];  iters [B];
+ *   kkt [B, 4] = {scaled NLP error, max |constraint violation|, max |dual infeasibility| (unscaled), final mu}
+ *   lam_g [B, ng] = res['lam_g'];  lam_x [B, nz] = res['lam_x']   (IPOPT sign convention)
+ * Host pointers; copies in and out go over the handle's stream. */
+int mpcb_solve(mpcb_handle* h, int32_t B,
+               const double* x0, const double* xs,
+               const double* obs, int32_t obs_kind,
+               const double* z0,
+               double* z, double* obj, int32_t* status, int32_t* iters, double* kkt,
+               double* lam_g, double* lam_x);
+
+/* Same, with every pointer a DEVICE pointer on the handle's device (buffers owned by the caller, e.g.
+ * allocated with mpcb_dev_alloc or by any other HIP allocator).  Asynchronous on the handle's stream
+ * unless `sync` != 0.  This is the entry bench.py times: inputs already resident in HBM. */
+int mpcb_solve_device(mpcb_handle* h, int32_t B,
+                      const double* d_x0, const double* d_xs,
+                      const double* d_obs, int32_t obs_kind,
+                      const double* d_z0,
+                      double* d_z, double* d_obj, int32_t* d_status, int32_t* d_iters, double* d_kkt,
+                      double* d_lam_g, double* d_lam_x, int32_t sync);
+
+/* Closed loop on the device: `steps` receding-horizon iterations of  solve -> apply U_0 with the plant
+ * x0 <- x0 + T f(x0,U_0) -> shift warm start -> advance obstacles   (main_cbf_kin_c_sim.py:87-123,16-26;
+ * main_cbf_kin_c_sim_pre.py:98-106).  Host pointers.
+ *   obs_state [B, n_obs, 6] in/out (constant-velocity obstacles, Obs_prediction.py:27-30; v = 0 keeps them static)
+ *   predict   1: rows use the predicted position per node (kin_pre.py:239-247); 0: rows use the current position
+ *   x_hist [B, steps+1, nx], u_hist [B, steps, 2] (may be NULL), status_hist [B, steps], iters_hist [B, steps] */
+int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps,
+                     const double* x0, const double* xs, double* obs_state, int32_t predict,
+                     double* x_hist, double* u_hist, int32_t* status_hist, int32_t* iters_hist);
+
+/* device memory helpers so that Python (ctypes, no torch) can keep batches resident */
+int mpcb_dev_alloc(mpcb_handle* h, uint64_t bytes, void** dptr);
+int mpcb_dev_free(mpcb_handle* h, void* dptr);
+int mpcb_dev_upload(mpcb_handle* h, void* dptr, const void* src, uint64_t bytes);
+int mpcb_dev_download(mpcb_handle* h, void* dst, const void* dptr, uint64_t bytes);
+int mpcb_sync(mpcb_handle* h);
+
+/* HIP-event timing of the solve kernel on the handle's stream since the last reset:
+ * number of launches, total and last kernel milliseconds. */
+int mpcb_timing(mpcb_handle* h, int32_t reset, int32_t* launches, double* total_ms, double* last_ms);
+
+/* Model right-hand side f(x,u) on the host (the `mpc_solver.f` the drivers call for the plant step,
+ * main_cbf_kin_c_sim.py:17).  Tiny, scalar, no device involved. */
+int mpcb_model_rhs(const mpcb_config* cfg, const double* x, const double* u, double* xdot);
+
+const char* mpcb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCBATCH_H */

@@ -1,0 +1,88 @@
+// mpcb_wave.h — the cross-lane primitives the solver kernel is written against.
+//
+// Device build (hipcc, gfx950): thin wrappers over wave64 intrinsics; one 64-thread workgroup = one
+// wavefront = one problem instance, so "sync" is a single-wave barrier that only orders LDS traffic.
+//
+// MPCB_WAVE_EMU build (g++; used ONLY by tests/emu to step the kernel source on a CPU, never shipped in
+// libmpcbatch.so): every lane is a host thread, cross-lane traffic goes through a shared exchange array
+// guarded by a barrier.  Reductions use the same xor-butterfly association order as the device code so
+// that wave-uniform decisions are identical.
+#pragma once
+
+#ifndef MPCB_WAVE_EMU
+#include <hip/hip_runtime.h>
+#define MPCB_DEV __device__ __forceinline__
+#define MPCB_DEVFN __device__
+
+namespace wv {
+MPCB_DEV int lane() { return (int)threadIdx.x; }
+MPCB_DEV void sync() { __syncthreads(); }
+MPCB_DEV double shfl(double v, int src) { return __shfl(v, src, 64); }
+MPCB_DEV int shfl(int v, int src) { return __shfl(v, src, 64); }
+// value of lane `src` (wave-uniform index) in every lane
+MPCB_DEV double bcast(double v, int src) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+MPCB_DEV double sum(double v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+MPCB_DEV double max(double v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = fmax(v, __shfl_xor(v, m, 64));
+  return v;
+}
+MPCB_DEV double min(double v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = fmin(v, __shfl_xor(v, m, 64));
+  return v;
+}
+MPCB_DEV bool any(bool p) { return __any(p) != 0; }
+MPCB_DEV bool all(bool p) { return __all(p) != 0; }
+}  // namespace wv
+
+#else  // ------------------------------------------------------------------ host emulation (tests only)
+#include <barrier>
+#include <cmath>
+#define MPCB_DEV inline
+#define MPCB_DEVFN
+
+namespace wv {
+struct Emu {
+  std::barrier<>* bar;
+  double xd[64];
+  int xi[64];
+};
+extern thread_local int t_lane;
+extern thread_local Emu* t_emu;
+inline int lane() { return t_lane; }
+inline void sync() { t_emu->bar->arrive_and_wait(); }
+inline double shfl(double v, int src) {
+  t_emu->xd[t_lane] = v; sync();
+  double r = t_emu->xd[src & 63]; sync();
+  return r;
+}
+inline int shfl(int v, int src) {
+  t_emu->xi[t_lane] = v; sync();
+  int r = t_emu->xi[src & 63]; sync();
+  return r;
+}
+inline double bcast(double v, int src) { return shfl(v, src); }
+template <class Op> inline double reduce(double v, Op op) {
+  t_emu->xd[t_lane] = v; sync();
+  double t[64];
+  for (int i = 0; i < 64; ++i) t[i] = t_emu->xd[i];
+  for (int n = 64; n > 1; n >>= 1) for (int i = 0; i < n / 2; ++i) t[i] = op(t[2 * i], t[2 * i + 1]);
+  sync();
+  return t[0];
+}
+inline double sum(double v) { return reduce(v, [](double a, double b) { return a + b; }); }
+inline double max(double v) { return reduce(v, [](double a, double b) { return std::fmax(a, b); }); }
+inline double min(double v) { return reduce(v, [](double a, double b) { return std::fmin(a, b); }); }
+inline bool any(bool p) { return sum(p ? 1.0 : 0.0) > 0.0; }
+inline bool all(bool p) { return sum(p ? 0.0 : 1.0) == 0.0; }
+}  // namespace wv
+#endif

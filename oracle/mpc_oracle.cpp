@@ -1,0 +1,1027 @@
+// oracle/mpc_oracle.cpp — CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's library
+// (oracle/_build/libmpcoracle.so).  The product path (mpc_motion_planning_amd/, libmpcbatch.so) never
+// links, imports or calls it and has no CPU fallback.
+//
+// PARITY STATUS: "parity unpinned" versus the reference's own solver.  The arithmetic of the reference's hot
+// path lives in the third-party `casadi` wheel (bundled IPOPT + MUMPS; no version pinned anywhere in the
+// reference: no requirements.txt / setup.py / lockfile), which is absent from /root/reference, is not installed
+// in this image and cannot be fetched (no network).  The reference holds no tests, golden vectors or result
+// files for this path either.  What this file restates, scalar and dependency-free:
+//   (1) the NLP exactly as the reference builds it — model, cost, rows, bounds and orderings —
+//         CasaDi_MPC_Optimize_Multishoot/MPC_CBF_optimize_kin.py:84-134 (bounds), :136-255 (model/cost/rows)
+//         CasaDi_MPC_Optimize_Multishoot/MPC_CBF_optimize_kin_pre.py:236-253 (predicted obstacles)
+//         CasaDi_MPC_Optimize_Multishoot/MPC_CBF_optimize_dyn.py:85-135,137-250 (dynamic model)
+//   (2) IPOPT's published algorithm (Waechter & Biegler, Math. Program. 106 (2006) 25-57: primal-dual
+//       barrier method, monotone mu, fraction-to-boundary rule, filter line search, inertia correction,
+//       gradient-based objective scaling, bound push / bound relaxation) with the option values the reference
+//       passes (kin.py:252-253: max_iter 100, acceptable_tol 1e-8) and IPOPT's documented defaults otherwise.
+// Results are pinned instead by (a) an independent numpy KKT certificate (oracle/kkt_check.py) and (b) an
+// independent dense numpy interior-point solver (oracle/dense_ipm.py) on the reference's flat z / g ordering.
+//
+// Deliberate differences from IPOPT (none changes the KKT point that is reached in a given basin):
+//   - X_0 is eliminated (it is pinned by the rows X_0 - P[0:nx] = 0, kin.py:191); rows that only involve X_0
+//     are constants and are reported with zero multipliers.
+//   - the KKT system is solved by a Riccati recursion over the stages (state augmented with the previous
+//     control because of the (U_i - U_{i-1}) cost and rate rows, kin.py:201-204,216) instead of MUMPS.
+//   - no restoration phase: a failed line search ends with MPCB_ST_LINESEARCH.
+//   - multipliers of the slack equalities are eliminated (y_d = v_L - v_U); no constraint-row scaling
+//     (every row gradient of this NLP is < max_gradient at sane scenes).
+//
+// Build: see oracle/Makefile  (g++ -O2 -fopenmp -shared -fPIC).
+
+#include "../include/mpcbatch.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+extern "C" int mpco_dims(const mpcb_config* c, int32_t* nx, int32_t* nz, int32_t* ng);
+
+namespace {
+
+constexpr int NXM = MPCB_NX_MAX;      // 6
+constexpr int NU = MPCB_NU;           // 2
+constexpr int NVM = NXM + NU;         // model variables [X, U]
+constexpr int NAM = NXM + NU;         // augmented state [X, Uprev]
+constexpr int NWM = NAM + NU;         // stage variables [X, Uprev, U]
+constexpr int NODES = MPCB_N_MAX + 1; // 64
+constexpr int NOBM = MPCB_NOBS_MAX;
+constexpr double INF = std::numeric_limits<double>::infinity();
+
+// ---------------------------------------------------------------------------------------------------------
+// Second-order forward-mode AD over NV independent variables (value, gradient, Hessian).  Used to
+// differentiate the model right-hand sides exactly as the reference writes them, and to cross-check the
+// hand-written kinematic derivatives.
+// ---------------------------------------------------------------------------------------------------------
+template <int NV>
+struct D2 {
+  double v;
+  double g[NV];
+  double h[NV][NV];
+  D2() : v(0) { std::memset(g, 0, sizeof g); std::memset(h, 0, sizeof h); }
+  D2(double c) : v(c) { std::memset(g, 0, sizeof g); std::memset(h, 0, sizeof h); }
+  static D2 var(double x, int i) { D2 r(x); r.g[i] = 1.0; return r; }
+  // r = phi(a) given phi, phi', phi''
+  static D2 chain(const D2& a, double p, double p1, double p2) {
+    D2 r; r.v = p;
+    for (int i = 0; i < NV; ++i) r.g[i] = p1 * a.g[i];
+    for (int i = 0; i < NV; ++i) for (int j = 0; j < NV; ++j) r.h[i][j] = p1 * a.h[i][j] + p2 * a.g[i] * a.g[j];
+    return r;
+  }
+};
+template <int NV> D2<NV> operator+(const D2<NV>& a, const D2<NV>& b) {
+  D2<NV> r; r.v = a.v + b.v;
+  for (int i = 0; i < NV; ++i) r.g[i] = a.g[i] + b.g[i];
+  for (int i = 0; i < NV; ++i) for (int j = 0; j < NV; ++j) r.h[i][j] = a.h[i][j] + b.h[i][j];
+  return r;
+}
+template <int NV> D2<NV> operator-(const D2<NV>& a, const D2<NV>& b) {
+  D2<NV> r; r.v = a.v - b.v;
+  for (int i = 0; i < NV; ++i) r.g[i] = a.g[i] - b.g[i];
+  for (int i = 0; i < NV; ++i) for (int j = 0; j < NV; ++j) r.h[i][j] = a.h[i][j] - b.h[i][j];
+  return r;
+}
+template <int NV> D2<NV> operator-(const D2<NV>& a) { return D2<NV>(0.0) - a; }
+template <int NV> D2<NV> operator*(const D2<NV>& a, const D2<NV>& b) {
+  D2<NV> r; r.v = a.v * b.v;
+  for (int i = 0; i < NV; ++i) r.g[i] = a.g[i] * b.v + a.v * b.g[i];
+  for (int i = 0; i < NV; ++i) for (int j = 0; j < NV; ++j)
+    r.h[i][j] = a.h[i][j] * b.v + a.v * b.h[i][j] + a.g[i] * b.g[j] + a.g[j] * b.g[i];
+  return r;
+}
+template <int NV> D2<NV> operator/(const D2<NV>& a, const D2<NV>& b) {
+  double ib = 1.0 / b.v;
+  D2<NV> rb = D2<NV>::chain(b, ib, -ib * ib, 2.0 * ib * ib * ib);
+  return a * rb;
+}
+template <int NV> D2<NV> operator*(double c, const D2<NV>& a) { return D2<NV>(c) * a; }
+template <int NV> D2<NV> operator*(const D2<NV>& a, double c) { return a * D2<NV>(c); }
+template <int NV> D2<NV> operator/(const D2<NV>& a, double c) { return a * D2<NV>(1.0 / c); }
+template <int NV> D2<NV> operator/(double c, const D2<NV>& a) { return D2<NV>(c) / a; }
+template <int NV> D2<NV> operator+(const D2<NV>& a, double c) { return a + D2<NV>(c); }
+template <int NV> D2<NV> operator+(double c, const D2<NV>& a) { return a + D2<NV>(c); }
+template <int NV> D2<NV> operator-(const D2<NV>& a, double c) { return a - D2<NV>(c); }
+template <int NV> D2<NV> operator-(double c, const D2<NV>& a) { return D2<NV>(c) - a; }
+template <int NV> D2<NV> sin(const D2<NV>& a) { return D2<NV>::chain(a, std::sin(a.v), std::cos(a.v), -std::sin(a.v)); }
+template <int NV> D2<NV> cos(const D2<NV>& a) { return D2<NV>::chain(a, std::cos(a.v), -std::sin(a.v), -std::cos(a.v)); }
+template <int NV> D2<NV> tan(const D2<NV>& a) {
+  double t = std::tan(a.v), s2 = 1.0 + t * t;
+  return D2<NV>::chain(a, t, s2, 2.0 * t * s2);
+}
+using std::cos; using std::sin; using std::tan;
+
+// ---------------------------------------------------------------------------------------------------------
+// Model right-hand sides, written once for double and for D2 (the reference's CasADi expressions).
+// ---------------------------------------------------------------------------------------------------------
+// CMOM/MPC_CBF_optimize_kin.py:153-156   rhs = [vx cos(phi), vx sin(phi), vx tan(df)/Veh_l, ax]
+template <class S>
+void rhs_kin(const mpcb_config& c, const S* x, const S* u, S* o) {
+  o[0] = x[3] * cos(x[2]);
+  o[1] = x[3] * sin(x[2]);
+  o[2] = x[3] * tan(u[0]) / c.veh_l;
+  o[3] = u[1];
+}
+// CMOM/MPC_CBF_optimize_dyn.py:156-170
+template <class S>
+void rhs_dyn(const mpcb_config& c, const S* x, const S* u, S* o) {
+  const S &phi = x[2], &vx = x[3], &vy = x[4], &r = x[5], &df = u[0], &ax = u[1];
+  S alpha_f = df - (vy + c.veh_lf * r) / vx;
+  S alpha_r = -(vy - c.veh_lr * r) / vx;
+  S Cf = (c.Fymax_f * 2.0 * c.aopt_f) / (c.aopt_f * c.aopt_f + alpha_f * alpha_f);
+  S Cr = (c.Fymax_r * 2.0 * c.aopt_r) / (c.aopt_r * c.aopt_r + alpha_r * alpha_r);
+  S Fcf = -(Cf * alpha_f);
+  S Fcr = -(Cr * alpha_r);
+  o[0] = vx * cos(phi) - vy * sin(phi);
+  o[1] = vx * sin(phi) + vy * cos(phi);
+  o[2] = r;
+  o[3] = ax + r * vy;
+  o[4] = -(r * vx) + (2.0 / c.veh_m) * (Fcf * cos(df) + Fcr);
+  o[5] = (2.0 / c.veh_Iz) * (c.veh_lf * Fcf - c.veh_lr * Fcr);
+}
+
+inline int nx_of(const mpcb_config& c) { return c.model == MPCB_MODEL_DYN ? 6 : 4; }
+
+void rhs_any(const mpcb_config& c, const double* x, const double* u, double* o) {
+  if (c.model == MPCB_MODEL_DYN) rhs_dyn<double>(c, x, u, o); else rhs_kin<double>(c, x, u, o);
+}
+
+struct ModelEval {
+  double F[NXM];          // X + T f(X,U)   (explicit Euler, kin.py:207 / dyn.py:227)
+  double A[NXM][NXM];     // dF/dX
+  double B[NXM][NU];      // dF/dU
+};
+
+// F, A, B and (optionally) Hc = sum_a lam[a] * d2F_a/d[X,U]^2 by AD
+void model_eval_ad(const mpcb_config& c, const double* X, const double* U, const double* lam, ModelEval& me,
+                   double Hc[NVM][NVM]) {
+  const int nx = nx_of(c);
+  typedef D2<NVM> S;
+  S x[NXM], u[NU], o[NXM];
+  for (int i = 0; i < nx; ++i) x[i] = S::var(X[i], i);
+  for (int i = 0; i < NU; ++i) u[i] = S::var(U[i], nx + i);
+  if (c.model == MPCB_MODEL_DYN) rhs_dyn<S>(c, x, u, o); else rhs_kin<S>(c, x, u, o);
+  for (int a = 0; a < nx; ++a) {
+    me.F[a] = X[a] + c.T * o[a].v;
+    for (int j = 0; j < nx; ++j) me.A[a][j] = (a == j ? 1.0 : 0.0) + c.T * o[a].g[j];
+    for (int j = 0; j < NU; ++j) me.B[a][j] = c.T * o[a].g[nx + j];
+  }
+  if (Hc) {
+    for (int i = 0; i < NVM; ++i) for (int j = 0; j < NVM; ++j) Hc[i][j] = 0.0;
+    if (lam)
+      for (int a = 0; a < nx; ++a)
+        for (int i = 0; i < nx + NU; ++i) for (int j = 0; j < nx + NU; ++j) Hc[i][j] += lam[a] * c.T * o[a].h[i][j];
+  }
+}
+
+// hand-written kinematic derivatives (what the HIP kernel also codes); checked against AD in tests
+void model_eval_kin(const mpcb_config& c, const double* X, const double* U, const double* lam, ModelEval& me,
+                    double Hc[NVM][NVM]) {
+  const double T = c.T, il = 1.0 / c.veh_l;
+  const double phi = X[2], v = X[3], df = U[0], a = U[1];
+  const double sp = std::sin(phi), cp = std::cos(phi), td = std::tan(df), sec2 = 1.0 + td * td;
+  me.F[0] = X[0] + T * v * cp;
+  me.F[1] = X[1] + T * v * sp;
+  me.F[2] = X[2] + T * v * td * il;
+  me.F[3] = X[3] + T * a;
+  for (int i = 0; i < NXM; ++i) for (int j = 0; j < NXM; ++j) me.A[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int i = 0; i < NXM; ++i) for (int j = 0; j < NU; ++j) me.B[i][j] = 0.0;
+  me.A[0][2] = -T * v * sp; me.A[0][3] = T * cp;
+  me.A[1][2] = T * v * cp;  me.A[1][3] = T * sp;
+  me.A[2][3] = T * td * il;
+  me.B[2][0] = T * v * sec2 * il;
+  me.B[3][1] = T;
+  if (Hc) {
+    for (int i = 0; i < NVM; ++i) for (int j = 0; j < NVM; ++j) Hc[i][j] = 0.0;
+    if (lam) {
+      // variable order [x, y, phi, v, df, a]
+      Hc[2][2] = T * (-lam[0] * v * cp - lam[1] * v * sp);
+      Hc[2][3] = Hc[3][2] = T * (-lam[0] * sp + lam[1] * cp);
+      Hc[3][4] = Hc[4][3] = T * lam[2] * sec2 * il;
+      Hc[4][4] = T * lam[2] * v * 2.0 * td * sec2 * il;
+    }
+  }
+}
+
+void model_eval(const mpcb_config& c, const double* X, const double* U, const double* lam, ModelEval& me,
+                double Hc[NVM][NVM], bool force_ad = false) {
+  if (c.model == MPCB_MODEL_KIN && !force_ad) model_eval_kin(c, X, U, lam, me, Hc);
+  else model_eval_ad(c, X, U, lam, me, Hc);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Inequality item: value c(w) with  L <= c <= U,  slack s (for a variable box s IS the variable),
+// duals vL, vU of s - L >= 0 and U - s >= 0.
+// ---------------------------------------------------------------------------------------------------------
+struct Ineq {
+  bool on = false, hasL = false, hasU = false;
+  double L = -INF, U = INF;
+  double s = 0, vL = 0, vU = 0;
+  double r = 0;                  // c(w) - s   (0 for boxes)
+  double ds = 0, dvL = 0, dvU = 0;
+  double tL = 0, tU = 0;         // complementarity targets of the current solve
+  // gradient wrt the stage vector [X, Uprev, U]: at most two nonzeros
+  int i0 = -1, i1 = -1; double g0 = 0, g1 = 0;
+  double y() const { return (hasL ? vL : 0.0) - (hasU ? vU : 0.0); }
+};
+
+struct ObsP { double ox, oy, ix2, iy2; };   // centre and 1/sX^2, 1/sY^2
+
+struct Opt {   // line-search / barrier constants of IPOPT (Waechter-Biegler 2006, and IPOPT's option defaults)
+  double kappa_eps = 10.0, kappa_mu = 0.2, theta_mu = 1.5, tau_min = 0.99;
+  double gamma_theta = 1e-5, gamma_phi = 1e-8, delta = 1.0, s_theta = 1.1, s_phi = 2.3, eta_phi = 1e-8;
+  double gamma_alpha = 0.05, kappa_sigma = 1e10, s_max = 100.0;
+  double dw_first = 1e-4, dw_min = 1e-20, dw_max = 1e40, kw_minus = 1.0 / 3.0, kw_plus = 8.0, kw_plus_first = 100.0;
+};
+
+struct Solver {
+  const mpcb_config& c;
+  Opt o;
+  int N, nx, na, nw, nobs;
+  const double *x0, *xs;
+  ObsP obs[NODES][NOBM];
+  bool obs_node[NODES];
+
+  // iterate
+  double X[NODES][NXM], U[NODES][NU], lam[NODES][NXM];
+  Ineq bU[NODES][NU], bX[NODES][NXM], rR[NODES][NU], rO[NODES][NOBM];
+  double os = 1.0, mu = 0.1, tau = 0.99;
+
+  // evaluation at the iterate
+  ModelEval me[NODES];
+  double dfc[NODES][NXM];          // defect F_k - X_{k+1}
+  double fval = 0, theta = 0;
+
+  // step
+  double dX[NODES][NXM], dU[NODES][NU], lamF[NODES][NXM];
+  double Kg[NODES][NU][NAM], kf[NODES][NU], P[NODES][NAM][NAM], p[NODES][NAM], Mi[NODES][3];
+  double H[NODES][NWM][NWM], g[NODES][NWM];
+  double dw_last = 0.0, dw_used = 0.0;
+  bool debug = std::getenv("MPCO_DEBUG") != nullptr;
+
+  std::vector<std::pair<double, double>> filter;
+  double theta_max = 0, theta_min = 0;
+
+  int iters = 0, status = MPCB_ST_MAXITER;
+  double err0 = 0;
+  int n_dyn_eval = 0, n_factor = 0, n_trial = 0;
+
+  Solver(const mpcb_config& cfg) : c(cfg) {
+    if (std::getenv("MPCO_KSIG")) o.kappa_sigma = std::atof(std::getenv("MPCO_KSIG"));
+    N = c.N; nx = nx_of(c); na = nx + NU; nw = na + NU; nobs = c.n_obs;
+  }
+
+  // ----- item enumeration --------------------------------------------------------------------------------
+  template <class F> void each_item(int k, F&& f) {
+    if (k < N) for (int i = 0; i < NU; ++i) if (bU[k][i].on) f(bU[k][i]);
+    if (k >= 1) for (int i = 0; i < nx; ++i) if (bX[k][i].on) f(bX[k][i]);
+    if (k >= 1 && k < N) for (int i = 0; i < NU; ++i) if (rR[k][i].on) f(rR[k][i]);
+    if (k >= 1 && obs_node[k]) for (int j = 0; j < nobs; ++j) if (rO[k][j].on) f(rO[k][j]);
+  }
+
+  double hval(int k, int j, const double* Xk) const {
+    const ObsP& q = obs[k][j];
+    double dx = Xk[0] - q.ox, dy = Xk[1] - q.oy;
+    return dx * dx * q.ix2 + dy * dy * q.iy2 - 1.0;
+  }
+
+  static void relax(const mpcb_config& c, Ineq& it) {
+    if (it.hasL) it.L -= c.bound_relax * std::max(1.0, std::fabs(it.L));
+    if (it.hasU) it.U += c.bound_relax * std::max(1.0, std::fabs(it.U));
+  }
+  double push(const Ineq& it, double v) const {
+    const double k1 = c.bound_push, k2 = c.bound_frac;
+    if (it.hasL && it.hasU) {
+      double pl = std::min(k1 * std::max(1.0, std::fabs(it.L)), k2 * (it.U - it.L));
+      double pu = std::min(k1 * std::max(1.0, std::fabs(it.U)), k2 * (it.U - it.L));
+      v = std::max(v, it.L + pl); v = std::min(v, it.U - pu);
+    } else if (it.hasL) v = std::max(v, it.L + k1 * std::max(1.0, std::fabs(it.L)));
+    else if (it.hasU) v = std::min(v, it.U - k1 * std::max(1.0, std::fabs(it.U)));
+    return v;
+  }
+  static void setup(Ineq& it, double L, double U) {
+    it = Ineq();
+    it.hasL = std::isfinite(L); it.hasU = std::isfinite(U);
+    it.on = it.hasL || it.hasU; it.L = L; it.U = U;
+  }
+
+  // ----- problem set-up ----------------------------------------------------------------------------------
+  // obstacles: static [nobs][6] or predicted [nobs][N+1][6]; rows [x,y,theta,v,l,w]
+  bool init(const double* x0_, const double* xs_, const double* ob, int obs_kind, const double* z0) {
+    x0 = x0_; xs = xs_;
+    const int last_row = c.obs_terminal ? N : N - 1;       // reference row index range 0..last_row
+    for (int k = 0; k <= N; ++k) {
+      obs_node[k] = false;
+      int step;                                             // obstacle sample used by the row at node k
+      if (c.obs_mode == MPCB_OBS_KEEPOUT) { obs_node[k] = (k <= last_row); step = k; }
+      else { obs_node[k] = (k >= 1 && k - 1 <= last_row); step = k - 1; }   // gamma = 1: row i is h_i(X_{i+1})
+      if (!obs_node[k] || nobs == 0) continue;
+      for (int j = 0; j < nobs; ++j) {
+        const double* q = (obs_kind == MPCB_OBSIN_PREDICTED) ? ob + ((size_t)j * (N + 1) + step) * 6 : ob + (size_t)j * 6;
+        double sx = c.obs_sx_fixed > 0 ? c.obs_sx_fixed : c.ego_hl + q[4] / 2 + c.safe_disl;   // kin.py:242
+        double sy = c.obs_sy_fixed > 0 ? c.obs_sy_fixed : c.ego_hw + q[5] / 2 + c.safe_disw;   // kin.py:243
+        obs[k][j] = ObsP{q[0], q[1], 1.0 / (sx * sx), 1.0 / (sy * sy)};
+      }
+    }
+    // iterate from z0 (reference order, kin.py:250), X_0 pinned
+    for (int k = 0; k < N; ++k) for (int i = 0; i < NU; ++i) U[k][i] = z0 ? z0[NU * k + i] : 0.0;
+    for (int k = 0; k <= N; ++k) for (int i = 0; i < nx; ++i) X[k][i] = z0 ? z0[NU * N + nx * k + i] : 0.0;
+    double X0guess[NXM]; for (int i = 0; i < nx; ++i) X0guess[i] = X[0][i];
+    for (int i = 0; i < nx; ++i) X[0][i] = x0[i];
+    for (int i = 0; i < NU; ++i) U[N][i] = 0.0;
+    std::memset(lam, 0, sizeof lam);
+
+    // objective scaling at the user's start (IPOPT gradient-based scaling, nlp_scaling_max_gradient)
+    {
+      double gmax = 0;
+      for (int k = 0; k < N; ++k) {
+        const double* Xk = (k == 0) ? X0guess : X[k];
+        for (int i = 0; i < nx; ++i) gmax = std::max(gmax, std::fabs(2 * c.Q[i] * (Xk[i] - xs[i])));
+        for (int i = 0; i < NU; ++i) {
+          double gu = 2 * c.R[i] * U[k][i];
+          const double* Up = (k == 0) ? c.u_last : U[k - 1];
+          if (k > 0 || c.du0_cost) gu += 2 * c.DR[i] * (U[k][i] - Up[i]);
+          if (k + 1 < N) gu -= 2 * c.DR[i] * (U[k + 1][i] - U[k][i]);
+          gmax = std::max(gmax, std::fabs(gu));
+        }
+      }
+      os = (gmax > c.max_gradient) ? c.max_gradient / gmax : 1.0;
+    }
+
+    // optional roll-out of X from x0 with the guessed (clipped) controls
+    if (c.init_rollout) {
+      for (int k = 0; k < N; ++k) {
+        double Uc[NU]; for (int i = 0; i < NU; ++i) Uc[i] = std::min(std::max(U[k][i], c.u_lo[i]), c.u_hi[i]);
+        double f[NXM]; rhs_any(c, X[k], Uc, f);
+        for (int i = 0; i < nx; ++i) X[k + 1][i] = X[k][i] + c.T * f[i];
+      }
+    }
+
+    // feasibility of the pinned node 0 (rows that IPOPT could never satisfy)
+    for (int i = 0; i < nx; ++i)
+      if (x0[i] < c.x_lo[i] - 1e-8 || x0[i] > c.x_hi[i] + 1e-8) { status = MPCB_ST_INFEASIBLE_X0; return false; }
+    if (obs_node[0]) for (int j = 0; j < nobs; ++j)
+      if (hval(0, j, x0) < c.obs_hmin - 1e-8) { status = MPCB_ST_INFEASIBLE_X0; return false; }
+
+    // boxes: relax (bound_relax_factor), push the start inside (bound_push / bound_frac), duals = 1
+    for (int k = 0; k <= N; ++k) {
+      for (int i = 0; i < NU; ++i) {
+        setup(bU[k][i], c.u_lo[i], c.u_hi[i]);
+        Ineq& it = bU[k][i]; it.on = it.on && k < N; if (!it.on) continue;
+        relax(c, it); U[k][i] = push(it, U[k][i]); it.s = U[k][i]; it.vL = it.vU = 1.0; it.i0 = na + i; it.g0 = 1.0;
+      }
+      for (int i = 0; i < nx; ++i) {
+        setup(bX[k][i], c.x_lo[i], c.x_hi[i]);
+        Ineq& it = bX[k][i]; it.on = it.on && k >= 1; if (!it.on) continue;
+        relax(c, it); X[k][i] = push(it, X[k][i]); it.s = X[k][i]; it.vL = it.vU = 1.0; it.i0 = i; it.g0 = 1.0;
+      }
+    }
+    // general rows: slack = row value at the pushed start, pushed inside its own bounds
+    for (int k = 0; k <= N; ++k) {
+      for (int i = 0; i < NU; ++i) {
+        setup(rR[k][i], c.du_lo[i], c.du_hi[i]);
+        Ineq& it = rR[k][i]; it.on = it.on && k >= 1 && k < N; if (!it.on) continue;
+        relax(c, it); it.s = push(it, U[k][i] - U[k - 1][i]); it.vL = it.vU = 1.0;
+        it.i0 = na + i; it.g0 = 1.0; it.i1 = nx + i; it.g1 = -1.0;
+      }
+      for (int j = 0; j < NOBM; ++j) {
+        Ineq& it = rO[k][j]; it = Ineq();
+        if (!(j < nobs && k >= 1 && obs_node[k])) continue;
+        setup(it, c.obs_hmin, INF);
+        relax(c, it); it.s = push(it, hval(k, j, X[k])); it.vL = 1.0; it.i0 = 0; it.i1 = 1;
+      }
+    }
+    mu = c.mu_init; tau = std::max(o.tau_min, 1.0 - mu);
+    if (c.mu_strategy == MPCB_MU_ADAPTIVE || std::getenv("MPCO_CENTER")) {   // centred start: v = mu0 / slack
+      for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) {
+        if (it.hasL) it.vL = mu / (it.s - it.L);
+        if (it.hasU) it.vU = mu / (it.U - it.s);
+      });
+    }
+    return true;
+  }
+
+  // ----- evaluation at the current iterate ------------------------------------------------------------------
+  double objective(const double Xa[][NXM], const double Ua[][NU]) const {   // unscaled, kin.py:195-205
+    double f = 0;
+    for (int k = 0; k < N; ++k) {
+      for (int i = 0; i < nx; ++i) { double e = Xa[k][i] - xs[i]; f += c.Q[i] * e * e; }
+      for (int i = 0; i < NU; ++i) {
+        f += c.R[i] * Ua[k][i] * Ua[k][i];
+        if (k > 0 || c.du0_cost) { double d = Ua[k][i] - (k ? Ua[k - 1][i] : c.u_last[i]); f += c.DR[i] * d * d; }
+      }
+    }
+    return f;
+  }
+
+  void eval_point() {
+    theta = 0;
+    for (int k = 0; k < N; ++k) {
+      model_eval(c, X[k], U[k], nullptr, me[k], nullptr); ++n_dyn_eval;
+      for (int i = 0; i < nx; ++i) { dfc[k][i] = me[k].F[i] - X[k + 1][i]; theta += std::fabs(dfc[k][i]); }
+    }
+    for (int k = 0; k <= N; ++k) {
+      for (int i = 0; i < NU; ++i) if (bU[k][i].on) { bU[k][i].s = U[k][i]; bU[k][i].r = 0; }
+      for (int i = 0; i < nx; ++i) if (bX[k][i].on) { bX[k][i].s = X[k][i]; bX[k][i].r = 0; }
+      for (int i = 0; i < NU; ++i) if (rR[k][i].on) { rR[k][i].r = (U[k][i] - U[k - 1][i]) - rR[k][i].s; theta += std::fabs(rR[k][i].r); }
+      for (int j = 0; j < nobs; ++j) if (rO[k][j].on) {
+        Ineq& it = rO[k][j]; const ObsP& q = obs[k][j];
+        it.r = hval(k, j, X[k]) - it.s; theta += std::fabs(it.r);
+        it.g0 = 2 * (X[k][0] - q.ox) * q.ix2; it.g1 = 2 * (X[k][1] - q.oy) * q.iy2;
+      }
+    }
+    fval = objective(X, U);
+  }
+
+  double barrier_phi(double f_unscaled, double mu_) {
+    double phi = os * f_unscaled;
+    for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) {
+      if (it.hasL) phi -= mu_ * std::log(it.s - it.L);
+      if (it.hasU) phi -= mu_ * std::log(it.U - it.s);
+    });
+    return phi;
+  }
+
+  // dual residual of the scaled problem, per variable;  returns E_mu pieces
+  struct Err { double dual = 0, prim = 0, comp = 0, sd = 1, sc = 1; };
+  Err kkt_error(double mu_, double* dual_unscaled = nullptr) {
+    Err e;
+    double sum_lam = 0, sum_v = 0; int n_lam = 0, n_v = 0;
+    for (int k = 0; k <= N; ++k) {
+      double rX[NXM] = {0}, rU[NU] = {0};
+      if (k >= 1) {
+        if (k < N) for (int i = 0; i < nx; ++i) rX[i] += os * 2 * c.Q[i] * (X[k][i] - xs[i]);
+        for (int i = 0; i < nx; ++i) { rX[i] -= lam[k][i]; sum_lam += std::fabs(lam[k][i]); ++n_lam; }
+        if (k < N) for (int i = 0; i < nx; ++i) for (int a = 0; a < nx; ++a) rX[i] += me[k].A[a][i] * lam[k + 1][a];
+      }
+      if (k < N) {
+        for (int i = 0; i < NU; ++i) {
+          rU[i] += os * 2 * c.R[i] * U[k][i];
+          if (k > 0 || c.du0_cost) rU[i] += os * 2 * c.DR[i] * (U[k][i] - (k ? U[k - 1][i] : c.u_last[i]));
+          if (k + 1 < N) rU[i] -= os * 2 * c.DR[i] * (U[k + 1][i] - U[k][i]);
+          for (int a = 0; a < nx; ++a) rU[i] += me[k].B[a][i] * lam[k + 1][a];
+          if (k + 1 < N && rR[k + 1][i].on) rU[i] += rR[k + 1][i].y();      // d(row k+1)/dU_k = -1
+        }
+      }
+      each_item(k, [&](Ineq& it) {
+        double y = it.y();
+        auto add = [&](int idx, double gg) {
+          if (idx < 0) return;
+          if (idx < nx) rX[idx] -= y * gg;
+          else if (idx >= na) rU[idx - na] -= y * gg;      // Uprev part is accounted at stage k-1 above
+        };
+        add(it.i0, it.g0); add(it.i1, it.g1);
+        if (it.hasL) { e.comp = std::max(e.comp, std::fabs((it.s - it.L) * it.vL - mu_)); sum_v += it.vL; ++n_v; }
+        if (it.hasU) { e.comp = std::max(e.comp, std::fabs((it.U - it.s) * it.vU - mu_)); sum_v += it.vU; ++n_v; }
+        e.prim = std::max(e.prim, std::fabs(it.r));
+      });
+      if (k >= 1) for (int i = 0; i < nx; ++i) e.dual = std::max(e.dual, std::fabs(rX[i]));
+      if (k < N) for (int i = 0; i < NU; ++i) e.dual = std::max(e.dual, std::fabs(rU[i]));
+      if (k < N) for (int i = 0; i < nx; ++i) e.prim = std::max(e.prim, std::fabs(dfc[k][i]));
+    }
+    e.sd = std::max(o.s_max, (sum_lam + sum_v) / std::max(1, n_lam + n_v)) / o.s_max;
+    e.sc = std::max(o.s_max, sum_v / std::max(1, n_v)) / o.s_max;
+    if (dual_unscaled) *dual_unscaled = e.dual / os;
+    return e;
+  }
+  double Emu(const Err& e) const { return std::max(e.dual / e.sd, std::max(e.prim, e.comp / e.sc)); }
+
+  // ----- condensed stage QP --------------------------------------------------------------------------------
+  // Per item the complementarity targets tL, tU: the plain barrier step uses tL = tU = mu; the affine
+  // (predictor) step 0; Mehrotra's corrector mu_t -/+ ds_aff * dv_aff.
+  // Hessian of the condensed stage QP (independent of mu and of the targets)
+  void build_stage_matrix(int k, double dw) {
+    double (*Hk)[NWM] = H[k];
+    for (int i = 0; i < NWM; ++i) for (int j = 0; j < NWM; ++j) Hk[i][j] = 0;
+    if (k >= 1 && k < N) for (int i = 0; i < nx; ++i) Hk[i][i] += os * 2 * c.Q[i];
+    if (k < N) {
+      for (int i = 0; i < NU; ++i) {
+        int iu = na + i, ip = nx + i;
+        Hk[iu][iu] += os * 2 * c.R[i];
+        if (k > 0 || c.du0_cost) { double w2 = os * 2 * c.DR[i]; Hk[iu][iu] += w2; Hk[ip][ip] += w2; Hk[iu][ip] -= w2; Hk[ip][iu] -= w2; }
+      }
+      double Hc[NVM][NVM];
+      ModelEval tmp;
+      model_eval(c, X[k], U[k], lam[k + 1], tmp, Hc);
+      auto map = [&](int i) { return i < nx ? i : na + (i - nx); };
+      for (int i = 0; i < nx + NU; ++i) for (int j = 0; j < nx + NU; ++j) Hk[map(i)][map(j)] += Hc[i][j];
+    }
+    each_item(k, [&](Ineq& it) {
+      double sig = 0;
+      if (it.hasL) sig += it.vL / (it.s - it.L);
+      if (it.hasU) sig += it.vU / (it.U - it.s);
+      int id[2] = {it.i0, it.i1}; double gg[2] = {it.g0, it.g1};
+      for (int a = 0; a < 2; ++a) if (id[a] >= 0)
+        for (int b = 0; b < 2; ++b) if (id[b] >= 0) Hk[id[a]][id[b]] += sig * gg[a] * gg[b];
+    });
+    if (k >= 1 && obs_node[k]) for (int j = 0; j < nobs; ++j) if (rO[k][j].on) {   // - y * d2h
+      double y = rO[k][j].y();
+      Hk[0][0] -= y * 2 * obs[k][j].ix2; Hk[1][1] -= y * 2 * obs[k][j].iy2;
+    }
+    if (k >= 1) for (int i = 0; i < nx; ++i) Hk[i][i] += dw;
+    if (k < N) for (int i = 0; i < NU; ++i) Hk[na + i][na + i] += dw;
+  }
+
+  // gradient of the condensed stage QP for the current targets
+  void build_stage_grad(int k) {
+    double* gk = g[k];
+    for (int i = 0; i < NWM; ++i) gk[i] = 0;
+    if (k >= 1 && k < N) for (int i = 0; i < nx; ++i) gk[i] += os * 2 * c.Q[i] * (X[k][i] - xs[i]);
+    if (k < N) for (int i = 0; i < NU; ++i) {
+      int iu = na + i, ip = nx + i;
+      gk[iu] += os * 2 * c.R[i] * U[k][i];
+      if (k > 0 || c.du0_cost) {
+        double d = U[k][i] - (k ? U[k - 1][i] : c.u_last[i]), w2 = os * 2 * c.DR[i];
+        gk[iu] += w2 * d; gk[ip] -= w2 * d;
+      }
+    }
+    each_item(k, [&](Ineq& it) {
+      double sig = 0, gb = 0;
+      if (it.hasL) { sig += it.vL / (it.s - it.L); gb += it.tL / (it.s - it.L); }
+      if (it.hasU) { sig += it.vU / (it.U - it.s); gb -= it.tU / (it.U - it.s); }
+      gb -= sig * it.r;
+      if (it.i0 >= 0) gk[it.i0] -= gb * it.g0;
+      if (it.i1 >= 0) gk[it.i1] -= gb * it.g1;
+    });
+  }
+
+  void stage_AB(int k, double AB[NAM][NWM]) const {
+    for (int a = 0; a < na; ++a) for (int j = 0; j < nw; ++j) AB[a][j] = 0;
+    for (int a = 0; a < nx; ++a) {
+      for (int j = 0; j < nx; ++j) AB[a][j] = me[k].A[a][j];
+      for (int j = 0; j < NU; ++j) AB[a][na + j] = me[k].B[a][j];
+    }
+    for (int j = 0; j < NU; ++j) AB[nx + j][na + j] = 1.0;
+  }
+
+  // matrix part of the backward Riccati sweep: P_k, K_k, inv(Muu_k).
+  // false when some Muu is not positive definite (wrong inertia of the KKT matrix)
+  bool riccati_matrix() {
+    for (int i = 0; i < na; ++i) for (int j = 0; j < na; ++j) P[N][i][j] = H[N][i][j];
+    for (int k = N - 1; k >= 0; --k) {
+      double AB[NAM][NWM]; stage_AB(k, AB);
+      double W[NAM][NWM];
+      for (int a = 0; a < na; ++a)
+        for (int j = 0; j < nw; ++j) { double s = 0; for (int b = 0; b < na; ++b) s += P[k + 1][a][b] * AB[b][j]; W[a][j] = s; }
+      double M[NWM][NWM];
+      for (int i = 0; i < nw; ++i)
+        for (int j = 0; j < nw; ++j) { double s = H[k][i][j]; for (int a = 0; a < na; ++a) s += AB[a][i] * W[a][j]; M[i][j] = s; }
+      double m11 = M[na][na], m12 = 0.5 * (M[na][na + 1] + M[na + 1][na]), m22 = M[na + 1][na + 1];
+      double det = m11 * m22 - m12 * m12;
+      if (!(m11 > 0) || !(det > 1e-14 * m11 * m22) || !std::isfinite(det)) return false;
+      Mi[k][0] = m22 / det; Mi[k][1] = -m12 / det; Mi[k][2] = m11 / det;
+      for (int j = 0; j < na; ++j) {
+        Kg[k][0][j] = -(Mi[k][0] * M[na][j] + Mi[k][1] * M[na + 1][j]);
+        Kg[k][1][j] = -(Mi[k][1] * M[na][j] + Mi[k][2] * M[na + 1][j]);
+      }
+      for (int i = 0; i < na; ++i)
+        for (int j = 0; j < na; ++j) P[k][i][j] = M[i][j] + M[i][na] * Kg[k][0][j] + M[i][na + 1] * Kg[k][1][j];
+      for (int i = 0; i < na; ++i) for (int j = i + 1; j < na; ++j) { double s = 0.5 * (P[k][i][j] + P[k][j][i]); P[k][i][j] = P[k][j][i] = s; }
+    }
+    return true;
+  }
+
+  // vector part: backward (p_k, kff_k) for the current gradient g, then the forward roll-out of the step
+  void riccati_vector() {
+    for (int i = 0; i < na; ++i) p[N][i] = g[N][i];
+    for (int k = N - 1; k >= 0; --k) {
+      double AB[NAM][NWM]; stage_AB(k, AB);
+      double q[NAM], m[NWM];
+      for (int a = 0; a < na; ++a) { double s = p[k + 1][a]; for (int b = 0; b < nx; ++b) s += P[k + 1][a][b] * dfc[k][b]; q[a] = s; }
+      for (int i = 0; i < nw; ++i) { double s = g[k][i]; for (int a = 0; a < na; ++a) s += AB[a][i] * q[a]; m[i] = s; }
+      kf[k][0] = -(Mi[k][0] * m[na] + Mi[k][1] * m[na + 1]);
+      kf[k][1] = -(Mi[k][1] * m[na] + Mi[k][2] * m[na + 1]);
+      for (int i = 0; i < na; ++i) p[k][i] = m[i] + Kg[k][0][i] * m[na] + Kg[k][1][i] * m[na + 1];
+    }
+    double dxa[NAM] = {0};
+    for (int i = 0; i < nx; ++i) dX[0][i] = 0;
+    for (int k = 0; k < N; ++k) {
+      for (int i = 0; i < NU; ++i) { double s = kf[k][i]; for (int j = 0; j < na; ++j) s += Kg[k][i][j] * dxa[j]; dU[k][i] = s; }
+      double nxt[NAM] = {0};
+      for (int a = 0; a < nx; ++a) {
+        double s = dfc[k][a];
+        for (int j = 0; j < nx; ++j) s += me[k].A[a][j] * dxa[j];
+        for (int j = 0; j < NU; ++j) s += me[k].B[a][j] * dU[k][j];
+        nxt[a] = s;
+      }
+      for (int j = 0; j < NU; ++j) nxt[nx + j] = dU[k][j];
+      for (int a = 0; a < na; ++a) dxa[a] = nxt[a];
+      for (int a = 0; a < nx; ++a) {
+        dX[k + 1][a] = dxa[a];
+        double s = p[k + 1][a]; for (int b = 0; b < na; ++b) s += P[k + 1][a][b] * dxa[b]; lamF[k + 1][a] = s;
+      }
+    }
+    // slack and dual steps
+    for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) {
+      auto comp = [&](int idx) -> double {
+        if (idx < 0) return 0.0;
+        if (idx < nx) return dX[k][idx];
+        if (idx < na) return k ? dU[k - 1][idx - nx] : 0.0;
+        return dU[k][idx - na];
+      };
+      it.ds = it.g0 * comp(it.i0) + it.g1 * comp(it.i1) + it.r;
+      if (it.hasL) { double d = it.s - it.L; it.dvL = it.tL / d - it.vL - it.vL / d * it.ds; }
+      if (it.hasU) { double d = it.U - it.s; it.dvU = it.tU / d - it.vU + it.vU / d * it.ds; }
+    });
+  }
+
+  void set_targets(double t) {
+    for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) { it.tL = t; it.tU = t; });
+  }
+  void solve_direction() { for (int k = 0; k <= N; ++k) build_stage_grad(k); riccati_vector(); }
+
+  // KKT matrix factorisation with IPOPT's inertia-correction schedule for delta_w
+  bool factorize() {
+    double dw = 0.0; bool first_try = true;
+    for (int tries = 0; tries < 60; ++tries) {
+      for (int k = 0; k <= N; ++k) build_stage_matrix(k, dw);
+      ++n_factor;
+      if (riccati_matrix()) { if (dw > 0) dw_last = dw; dw_used = dw; return true; }
+      if (first_try) { dw = (dw_last == 0.0) ? o.dw_first : std::max(o.dw_min, o.kw_minus * dw_last); first_try = false; }
+      else dw *= (dw_last == 0.0) ? o.kw_plus_first : o.kw_plus;
+      if (dw > o.dw_max) return false;
+    }
+    return false;
+  }
+
+  // ----- line search ------------------------------------------------------------------------------------------
+  struct Trial { double theta, phi, f; bool ok; };
+  Trial eval_trial(double alpha, double mu_) {
+    static thread_local double Xt[NODES][NXM], Ut[NODES][NU];
+    Trial t{0, 0, 0, true};
+    for (int k = 0; k <= N; ++k) {
+      for (int i = 0; i < nx; ++i) Xt[k][i] = X[k][i] + alpha * dX[k][i];
+      for (int i = 0; i < NU; ++i) Ut[k][i] = (k < N) ? U[k][i] + alpha * dU[k][i] : 0.0;
+    }
+    for (int k = 0; k < N; ++k) {
+      double f[NXM]; rhs_any(c, Xt[k], Ut[k], f); ++n_dyn_eval;
+      for (int i = 0; i < nx; ++i) t.theta += std::fabs(Xt[k][i] + c.T * f[i] - Xt[k + 1][i]);
+    }
+    t.f = objective(Xt, Ut);
+    double phi = os * t.f;
+    for (int k = 0; k <= N; ++k) {
+      auto bar = [&](const Ineq& it, double s) {
+        if (it.hasL) { double d = s - it.L; if (!(d > 0)) t.ok = false; else phi -= mu_ * std::log(d); }
+        if (it.hasU) { double d = it.U - s; if (!(d > 0)) t.ok = false; else phi -= mu_ * std::log(d); }
+      };
+      if (k < N) for (int i = 0; i < NU; ++i) if (bU[k][i].on) bar(bU[k][i], Ut[k][i]);
+      if (k >= 1) for (int i = 0; i < nx; ++i) if (bX[k][i].on) bar(bX[k][i], Xt[k][i]);
+      if (k >= 1 && k < N) for (int i = 0; i < NU; ++i) if (rR[k][i].on) {
+        double s = rR[k][i].s + alpha * rR[k][i].ds; bar(rR[k][i], s);
+        t.theta += std::fabs((Ut[k][i] - Ut[k - 1][i]) - s);
+      }
+      if (k >= 1 && obs_node[k]) for (int j = 0; j < nobs; ++j) if (rO[k][j].on) {
+        double s = rO[k][j].s + alpha * rO[k][j].ds; bar(rO[k][j], s);
+        t.theta += std::fabs(hval(k, j, Xt[k]) - s);
+      }
+    }
+    t.phi = phi;
+    if (!std::isfinite(t.theta) || !std::isfinite(t.phi)) t.ok = false;
+    return t;
+  }
+
+  bool filter_ok(double th, double ph) const {
+    for (auto& e : filter) if (th >= e.first && ph >= e.second) return false;
+    return true;
+  }
+
+  void step_lengths(double tau_, double& a_pr, double& a_du) {
+    a_pr = 1.0; a_du = 1.0;
+    for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) {
+      if (it.hasL) {
+        if (it.ds < 0) a_pr = std::min(a_pr, -tau_ * (it.s - it.L) / it.ds);
+        if (it.dvL < 0) a_du = std::min(a_du, -tau_ * it.vL / it.dvL);
+      }
+      if (it.hasU) {
+        if (it.ds > 0) a_pr = std::min(a_pr, tau_ * (it.U - it.s) / it.ds);
+        if (it.dvU < 0) a_du = std::min(a_du, -tau_ * it.vU / it.dvU);
+      }
+    });
+  }
+
+  double dir_deriv(double mu_) {   // directional derivative of the barrier function along (dX, dU, ds)
+    double dphi = 0;
+    for (int k = 0; k <= N; ++k) {
+      if (k >= 1 && k < N) for (int i = 0; i < nx; ++i) dphi += os * 2 * c.Q[i] * (X[k][i] - xs[i]) * dX[k][i];
+      if (k < N) for (int i = 0; i < NU; ++i) {
+        dphi += os * 2 * c.R[i] * U[k][i] * dU[k][i];
+        if (k > 0 || c.du0_cost) {
+          double d = U[k][i] - (k ? U[k - 1][i] : c.u_last[i]);
+          dphi += os * 2 * c.DR[i] * d * (dU[k][i] - (k ? dU[k - 1][i] : 0.0));
+        }
+      }
+      each_item(k, [&](Ineq& it) {
+        if (it.hasL) dphi -= mu_ * it.ds / (it.s - it.L);
+        if (it.hasU) dphi += mu_ * it.ds / (it.U - it.s);
+      });
+    }
+    return dphi;
+  }
+
+  // IPOPT's filter line search (Waechter-Biegler Alg. A, steps A-5) without second-order correction.
+  // Returns the accepted alpha, or 0 when alpha fell under alpha_min.
+  double line_search(double a_max, double mu_, double dphi, bool& armijo_type) {
+    const double phi0 = barrier_phi(fval, mu_), th0 = theta;
+    double a_min;
+    if (dphi < 0) {
+      a_min = std::min(o.gamma_theta, o.gamma_phi * th0 / (-dphi));
+      if (th0 <= theta_min) a_min = std::min(a_min, o.delta * std::pow(th0, o.s_theta) / std::pow(-dphi, o.s_phi));
+    } else a_min = o.gamma_theta;
+    a_min *= o.gamma_alpha;
+    double alpha = a_max; armijo_type = false;
+    while (true) {
+      Trial t = eval_trial(alpha, mu_);
+      ++n_trial;
+      if (t.ok && t.theta <= theta_max && filter_ok(t.theta, t.phi)) {
+        bool sw = dphi < 0 && alpha * std::pow(-dphi, o.s_phi) > o.delta * std::pow(th0, o.s_theta);
+        if (th0 <= theta_min && sw) {
+          if (t.phi <= phi0 + o.eta_phi * alpha * dphi || t.phi - phi0 <= 10 * 2.2e-16 * std::fabs(phi0)) { armijo_type = true; return alpha; }
+        } else if (t.theta <= (1 - o.gamma_theta) * th0 || t.phi <= phi0 - o.gamma_phi * th0) return alpha;
+      }
+      alpha *= 0.5;
+      if (alpha < a_min || alpha < 1e-16) return 0.0;
+    }
+  }
+
+  void apply_step(double alpha, double alpha_du, double mu_) {
+    for (int k = 0; k <= N; ++k) {
+      if (k >= 1) for (int i = 0; i < nx; ++i) { X[k][i] += alpha * dX[k][i]; lam[k][i] += alpha * (lamF[k][i] - lam[k][i]); }
+      if (k < N) for (int i = 0; i < NU; ++i) U[k][i] += alpha * dU[k][i];
+      each_item(k, [&](Ineq& it) {
+        it.s += alpha * it.ds;
+        if (it.hasL) it.vL += alpha_du * it.dvL;
+        if (it.hasU) it.vU += alpha_du * it.dvU;
+      });
+    }
+    // boxes: slack is the variable itself
+    for (int k = 0; k <= N; ++k) {
+      for (int i = 0; i < NU; ++i) if (bU[k][i].on) bU[k][i].s = U[k][i];
+      for (int i = 0; i < nx; ++i) if (bX[k][i].on) bX[k][i].s = X[k][i];
+      each_item(k, [&](Ineq& it) {   // IPOPT eq. (16): keep Sigma within kappa_Sigma of mu / slack^2
+        if (it.hasL) { double d = it.s - it.L; it.vL = std::max(std::min(it.vL, o.kappa_sigma * mu_ / d), mu_ / (o.kappa_sigma * d)); }
+        if (it.hasU) { double d = it.U - it.s; it.vU = std::max(std::min(it.vU, o.kappa_sigma * mu_ / d), mu_ / (o.kappa_sigma * d)); }
+      });
+    }
+  }
+
+  double avg_compl(double a_pr = 0, double a_du = 0) {
+    double sum = 0; int n = 0;
+    for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) {
+      if (it.hasL) { sum += (it.s - it.L + a_pr * it.ds) * (it.vL + a_du * it.dvL); ++n; }
+      if (it.hasU) { sum += (it.U - it.s - a_pr * it.ds) * (it.vU + a_du * it.dvU); ++n; }
+    });
+    return n ? sum / n : 0.0;
+  }
+
+  // ----- main loop ------------------------------------------------------------------------------------------
+  void solve() {
+    eval_point();
+    theta_max = 1e4 * std::max(1.0, theta); theta_min = 1e-4 * std::max(1.0, theta);
+    const double mu_floor = c.tol / (o.kappa_eps + 1.0);
+    status = MPCB_ST_MAXITER;
+    for (iters = 0;; ++iters) {
+      Err e0 = kkt_error(0.0);
+      err0 = Emu(e0);
+      if (err0 <= c.tol) { status = MPCB_ST_SOLVED; break; }
+      if (iters >= c.max_iter) { status = MPCB_ST_MAXITER; break; }
+      if (!factorize()) { status = MPCB_ST_NUMERIC; break; }
+
+      double a_pr, a_du, alpha = 0, dphi = 0; bool armijo_type = false;
+      if (c.mu_strategy == MPCB_MU_MONOTONE) {
+        // barrier parameter update (monotone, Fiacco-McCormick)
+        for (;;) {
+          Err em = kkt_error(mu);
+          if (Emu(em) <= o.kappa_eps * mu && mu > mu_floor) {
+            mu = std::max(mu_floor, std::min(o.kappa_mu * mu, std::pow(mu, o.theta_mu)));
+            tau = std::max(o.tau_min, 1.0 - mu);
+            filter.clear();
+          } else break;
+        }
+        set_targets(mu);
+        solve_direction();
+        step_lengths(tau, a_pr, a_du);
+        dphi = dir_deriv(mu);
+        alpha = line_search(a_pr, mu, dphi, armijo_type);
+      } else {
+        // Mehrotra probing: affine step -> centring sigma -> corrector.  mu never increases.
+        const double mu_cur = avg_compl();
+        set_targets(0.0);
+        solve_direction();
+        double aa_pr, aa_du; step_lengths(1.0, aa_pr, aa_du);
+        const double mu_aff = avg_compl(aa_pr, aa_du);
+        double sigma = std::pow(std::max(0.0, mu_aff / mu_cur), 3.0);
+        sigma = std::min(1.0, std::max(sigma, 1e-8));
+        double mu_t = std::max(mu_floor, sigma * mu_cur);
+        {
+          static const double kinf = std::getenv("MPCO_KINF") ? std::atof(std::getenv("MPCO_KINF")) : 0.0;
+          double einf = std::max(e0.dual / e0.sd, e0.prim);
+          mu_t = std::max(mu_t, kinf * einf);
+        }
+        if (debug) std::fprintf(stderr, "      mu_cur %.3e mu_aff %.3e sigma %.3e aa_pr %.3e aa_du %.3e\n", mu_cur, mu_aff, sigma, aa_pr, aa_du);
+        for (int attempt = 0; attempt < 4; ++attempt) {
+          if (attempt == 0) {
+            for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) {
+              static const double cc = std::getenv("MPCO_CORR") ? std::atof(std::getenv("MPCO_CORR")) : 1e30;
+              double cL = std::max(-cc * mu_t, std::min(cc * mu_t, -it.ds * it.dvL));
+              double cU = std::max(-cc * mu_t, std::min(cc * mu_t, it.ds * it.dvU));
+              it.tL = mu_t + cL;      // second-order term from the predictor
+              it.tU = mu_t + cU;
+            });
+          } else set_targets(mu_t);               // plain centring step
+          solve_direction();
+          tau = std::max(o.tau_min, 1.0 - mu_t);
+          step_lengths(tau, a_pr, a_du);
+          dphi = dir_deriv(mu_t);
+          filter.clear();
+          alpha = line_search(a_pr, mu_t, dphi, armijo_type);
+          if (alpha > 0) break;
+          if (attempt >= 1) mu_t = std::min(1e5, 10.0 * std::max(mu_t, mu_cur));   // re-centre harder
+        }
+        mu = mu_t;
+      }
+      if (debug) std::fprintf(stderr, "it %3d mu %.2e E0 %.3e th %.3e f %.8e a_pr %.3e a %.3e a_du %.3e dw %.1e dphi %.2e |F|=%zu\n",
+                              iters, mu, err0, theta, fval, a_pr, alpha, a_du, dw_used, dphi, filter.size());
+      if (debug) {
+        // report the blocking item
+        double best = 2; const Ineq* bi = nullptr; int bk = -1;
+        for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) {
+          double a = 2;
+          if (it.hasL && it.ds < 0) a = std::min(a, -(it.s - it.L) / it.ds);
+          if (it.hasU && it.ds > 0) a = std::min(a, (it.U - it.s) / it.ds);
+          if (a < best) { best = a; bi = &it; bk = k; }
+        });
+        if (bi) std::fprintf(stderr, "      block: node %d idx(%d,%d) s-L %.3e U-s %.3e ds %.3e vL %.3e vU %.3e r %.3e tL %.2e tU %.2e\n", bk, bi->i0, bi->i1,
+                             bi->s - bi->L, bi->U - bi->s, bi->ds, bi->vL, bi->vU, bi->r, bi->tL, bi->tU);
+      }
+      if (!(alpha > 0)) { status = MPCB_ST_LINESEARCH; break; }
+      if (!armijo_type) filter.emplace_back((1 - o.gamma_theta) * theta, barrier_phi(fval, mu) - o.gamma_phi * theta);
+      apply_step(alpha, a_du, mu);
+      eval_point();
+      if (!std::isfinite(theta) || !std::isfinite(fval)) { status = MPCB_ST_NUMERIC; break; }
+    }
+  }
+
+  // ----- outputs in the reference's ordering ----------------------------------------------------------------
+  void write(double* z, double* obj, int32_t* st, int32_t* it, double* kkt, double* lam_g, double* lam_x) {
+    const int nz = NU * N + nx * (N + 1);
+    if (z) {
+      for (int k = 0; k < N; ++k) for (int i = 0; i < NU; ++i) z[NU * k + i] = U[k][i];
+      for (int k = 0; k <= N; ++k) for (int i = 0; i < nx; ++i) z[NU * N + nx * k + i] = X[k][i];
+    }
+    if (obj) *obj = objective(X, U);
+    if (st) *st = status;
+    if (it) *it = iters;
+    if (kkt) {
+      double du = 0; Err e = kkt_error(0.0, &du);
+      kkt[0] = Emu(e); kkt[1] = e.prim; kkt[2] = du; kkt[3] = mu;
+    }
+    if (lam_x) {   // IPOPT: lam_x = z_U - z_L, unscaled
+      for (int i = 0; i < nz; ++i) lam_x[i] = 0;
+      for (int k = 0; k < N; ++k) for (int i = 0; i < NU; ++i) if (bU[k][i].on) lam_x[NU * k + i] = -bU[k][i].y() / os;
+      for (int k = 1; k <= N; ++k) for (int i = 0; i < nx; ++i) if (bX[k][i].on) lam_x[NU * N + nx * k + i] = -bX[k][i].y() / os;
+    }
+    if (lam_g) {
+      int ng = 0; mpco_dims(&c, nullptr, nullptr, &ng);
+      for (int i = 0; i < ng; ++i) lam_g[i] = 0;
+      // multiplier of row (X_k - F_{k-1}) is -lam_k (Riccati sign) / os
+      int nrate = 0; for (int i = 0; i < NU; ++i) if (std::isfinite(c.du_lo[i]) || std::isfinite(c.du_hi[i])) ++nrate;
+      std::vector<int> dyn_row(N + 1), rate_row(N + 1, -1);
+      int r = nx;
+      if (!c.rate_interleaved) {
+        for (int k = 1; k <= N; ++k) { dyn_row[k] = r; r += nx; }
+        for (int k = 1; k < N; ++k) { rate_row[k] = r; r += nrate; }
+      } else {
+        for (int i = 0; i < N; ++i) { dyn_row[i + 1] = r; r += nx; if (i > 0) { rate_row[i] = r; r += nrate; } }
+      }
+      for (int k = 1; k <= N; ++k) for (int i = 0; i < nx; ++i) lam_g[dyn_row[k] + i] = -lam[k][i] / os;
+      // initial-condition rows: stationarity wrt X_0
+      for (int i = 0; i < nx; ++i) {
+        double s = -2 * c.Q[i] * (X[0][i] - xs[i]);
+        for (int a = 0; a < nx; ++a) s -= me[0].A[a][i] * lam[1][a] / os;
+        lam_g[i] = s;
+      }
+      for (int k = 1; k < N; ++k) { int q = 0; for (int i = 0; i < NU; ++i) if (rR[k][i].on) lam_g[rate_row[k] + q++] = -rR[k][i].y() / os; }
+      const int last_row = c.obs_terminal ? N : N - 1;
+      for (int i = 0; i <= last_row; ++i) {
+        int k = (c.obs_mode == MPCB_OBS_KEEPOUT) ? i : i + 1;
+        for (int j = 0; j < nobs; ++j) if (k >= 1 && k <= N && rO[k][j].on) lam_g[r + i * nobs + j] = -rO[k][j].y() / os;
+      }
+    }
+  }
+};
+
+int check_cfg(const mpcb_config* c) {
+  if (!c || c->struct_size != sizeof(mpcb_config)) return MPCB_E_INVALID;
+  if (c->model != MPCB_MODEL_KIN && c->model != MPCB_MODEL_DYN) return MPCB_E_INVALID;
+  if (c->N < 1 || c->N > MPCB_N_MAX || c->n_obs < 0 || c->n_obs > MPCB_NOBS_MAX) return MPCB_E_INVALID;
+  if (!(c->T > 0) || !(c->tol > 0) || c->max_iter < 0) return MPCB_E_INVALID;
+  if (c->obs_mode == MPCB_OBS_DCBF && std::fabs(c->gamma - 1.0) > 1e-12) return MPCB_E_UNSUPPORTED;
+  return MPCB_OK;
+}
+
+}  // namespace
+
+// =============================================================================================================
+// C entry points (loaded with ctypes by tests / smoke / bench cpu_baseline).  Same argument meaning as
+// mpcb_solve in include/mpcbatch.h.
+// =============================================================================================================
+extern "C" {
+
+int mpco_default_config(mpcb_config* cfg, int32_t model, int32_t N, double T) {
+  if (!cfg) return MPCB_E_INVALID;
+  std::memset(cfg, 0, sizeof *cfg);
+  mpcb_config& c = *cfg;
+  c.struct_size = sizeof(mpcb_config); c.model = model; c.N = N; c.T = T;
+  c.n_obs = 0; c.obs_mode = MPCB_OBS_KEEPOUT; c.gamma = 1.0; c.max_iter = 100;
+  c.mu_strategy = MPCB_MU_MONOTONE; c.init_rollout = 0;
+  const double deg = M_PI / 180.0;
+  for (int i = 0; i < NXM; ++i) { c.x_lo[i] = -INF; c.x_hi[i] = INF; }
+  c.u_lo[0] = -35 * deg; c.u_hi[0] = 35 * deg; c.u_lo[1] = -3.0; c.u_hi[1] = 3.0;   // mpc_parameters.yaml:34-37
+  c.x_lo[1] = -1.0; c.x_hi[1] = 5.0; c.x_lo[3] = 0.0; c.x_hi[3] = 40.0;             // mpc_parameters.yaml:32-33,38-39
+  c.du_lo[0] = -5 * deg * T; c.du_hi[0] = 5 * deg * T;                               // mpc_parameters.yaml:48-49
+  c.du_lo[1] = -INF; c.du_hi[1] = INF;
+  c.ego_hl = 2.4; c.ego_hw = 0.9; c.safe_disl = 1.0; c.safe_disw = 0.5; c.veh_l = 2.6;
+  c.veh_m = 1575; c.veh_lf = 1.2; c.veh_lr = 1.6; c.veh_Iz = 2875;
+  c.aopt_f = 0.3490658503988659; c.aopt_r = 0.19198621771937624;
+  c.Fymax_f = -50000 * c.aopt_f / 2; c.Fymax_r = -50000 * c.aopt_r / 2;
+  if (model == MPCB_MODEL_KIN) {
+    double Q[4] = {1e1, 1e5, 3e5, 1e4}; std::memcpy(c.Q, Q, sizeof Q);               // kin.py:168-172
+    c.R[0] = 1e4; c.R[1] = 1e4; c.DR[0] = 1e5; c.DR[1] = 1e2; c.du0_cost = 1;        // kin.py:179-184
+    c.obs_terminal = 0; c.obs_hmin = 0.0; c.rate_interleaved = 0;
+  } else {
+    double Q[6] = {10, 1e5, 1e3, 1e3, 1, 1}; std::memcpy(c.Q, Q, sizeof Q);          // dyn.py:189-195
+    c.R[0] = 1e3; c.R[1] = 1e3; c.DR[0] = 5e3; c.DR[1] = 5e2; c.du0_cost = 0;        // dyn.py:204-209
+    c.x_lo[4] = -5.0; c.x_hi[4] = 5.0;                                                // mpc_parameters.yaml:44-45
+    c.du_lo[1] = -3.0 * T; c.du_hi[1] = 1.5 * T;                                      // mpc_parameters.yaml:46-47
+    c.obs_terminal = 1; c.obs_hmin = 1.0; c.obs_sx_fixed = 4.0; c.obs_sy_fixed = 1.0; c.rate_interleaved = 1;
+  }
+  c.tol = 1e-8; c.mu_init = 0.1; c.bound_push = 0.01; c.bound_frac = 0.01; c.bound_relax = 1e-8; c.max_gradient = 100.0;
+  return MPCB_OK;
+}
+
+int mpco_dims(const mpcb_config* c, int32_t* nx, int32_t* nz, int32_t* ng) {
+  if (!c) return MPCB_E_INVALID;
+  int n = nx_of(*c), nrate = 0;
+  for (int i = 0; i < NU; ++i) if (std::isfinite(c->du_lo[i]) || std::isfinite(c->du_hi[i])) ++nrate;
+  if (nx) *nx = n;
+  if (nz) *nz = NU * c->N + n * (c->N + 1);
+  if (ng) *ng = n * (c->N + 1) + nrate * (c->N - 1) + c->n_obs * (c->obs_terminal ? c->N + 1 : c->N);
+  return MPCB_OK;
+}
+
+int mpco_model_rhs(const mpcb_config* cfg, const double* x, const double* u, double* xdot) {
+  if (!cfg || !x || !u || !xdot) return MPCB_E_INVALID;
+  rhs_any(*cfg, x, u, xdot);
+  return MPCB_OK;
+}
+
+// Oracle batch solve: same arrays as mpcb_solve.  threads <= 0: all OpenMP threads.
+int mpco_solve(const mpcb_config* cfg, int32_t B, const double* x0, const double* xs, const double* obs,
+               int32_t obs_kind, const double* z0, double* z, double* obj, int32_t* status, int32_t* iters,
+               double* kkt, double* lam_g, double* lam_x, int32_t threads) {
+  int rc = check_cfg(cfg);
+  if (rc != MPCB_OK) return rc;
+  if (B < 0 || !x0 || !xs || !z || (cfg->n_obs > 0 && !obs)) return MPCB_E_INVALID;
+  int nx, nz, ng; mpco_dims(cfg, &nx, &nz, &ng);
+  const size_t obs_stride = (size_t)cfg->n_obs * 6 * (obs_kind == MPCB_OBSIN_PREDICTED ? cfg->N + 1 : 1);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : omp_get_max_threads())
+#endif
+  for (int b = 0; b < B; ++b) {
+    Solver* s = new Solver(*cfg);
+    bool ok = s->init(x0 + (size_t)b * nx, xs + (size_t)b * nx, obs ? obs + b * obs_stride : nullptr, obs_kind,
+                      z0 ? z0 + (size_t)b * nz : nullptr);
+    if (ok) s->solve(); else s->eval_point();
+    s->write(z + (size_t)b * nz, obj ? obj + b : nullptr, status ? status + b : nullptr, iters ? iters + b : nullptr,
+             kkt ? kkt + (size_t)b * 4 : nullptr, lam_g ? lam_g + (size_t)b * ng : nullptr,
+             lam_x ? lam_x + (size_t)b * nz : nullptr);
+    delete s;
+  }
+  return MPCB_OK;
+}
+
+// model derivatives for tests: F[nx], A[nx*nx], Bm[nx*2], Hc[(nx+2)^2] (= sum lam_a T d2f_a), ad = 1 -> AD path
+int mpco_model_eval(const mpcb_config* cfg, const double* X, const double* U, const double* lam, double* F, double* A,
+                    double* Bm, double* Hc, int32_t ad) {
+  if (check_cfg(cfg) != MPCB_OK) return MPCB_E_INVALID;
+  const int nx = nx_of(*cfg);
+  ModelEval me; double H[NVM][NVM];
+  model_eval(*cfg, X, U, lam, me, H, ad != 0);
+  for (int i = 0; i < nx; ++i) {
+    F[i] = me.F[i];
+    for (int j = 0; j < nx; ++j) A[i * nx + j] = me.A[i][j];
+    for (int j = 0; j < NU; ++j) Bm[i * NU + j] = me.B[i][j];
+  }
+  for (int i = 0; i < nx + NU; ++i) for (int j = 0; j < nx + NU; ++j) Hc[i * (nx + NU) + j] = H[i][j];
+  return MPCB_OK;
+}
+
+}  // extern "C"
