@@ -1,0 +1,153 @@
+"""Shared implementation of the three `MPC_optimize` drop-in classes.
+
+The reference's classes (CasaDi_MPC_Optimize_Multishoot/MPC_CBF_optimize_{kin,kin_pre,dyn}.py) describe the NLP
+symbolically with CasADi and hand it to IPOPT.  Here the same public surface — constructor reading
+mpc_parameters.yaml, `initialize_constraints`, `optimize_problem` returning a callable `solver`, the model
+function `f`, `num_states`, `num_controls`, `N_p`, `T_S` — sits on the HIP library through ctypes.  Nothing in
+this module computes a solution on the CPU.
+"""
+import numpy as np
+
+from . import _abi
+from .dm import DM
+from .helpers import load_config, find_params_file, horizon_steps, PARAMS_FILE
+from .solver import BatchSolver, default_config, model_rhs
+
+_RETURN_STATUS = {
+    _abi.ST_SOLVED: "Solve_Succeeded",
+    _abi.ST_MAXITER: "Maximum_Iterations_Exceeded",
+    _abi.ST_LINESEARCH: "Restoration_Failed",
+    _abi.ST_INFEASIBLE_X0: "Infeasible_Problem_Detected",
+    _abi.ST_NUMERIC: "Error_In_Step_Computation",
+}
+
+
+class ModelFunction:
+    """`mpc_solver.f(x, u)` -> DM (kin.py:159; called by shift_movement, main_cbf_kin_c_sim.py:17)."""
+
+    def __init__(self, cfg):
+        self._cfg = cfg
+
+    def __call__(self, x, u):
+        return DM(model_rhs(self._cfg, np.asarray(x, dtype=np.float64).reshape(-1), np.asarray(u, dtype=np.float64).reshape(-1)))
+
+
+class NlpSolver:
+    """What `optimize_problem` returns: callable like the object `ca.nlpsol(...)` gives (kin.py:254)."""
+
+    def __init__(self, owner, cfg, obs, obs_kind):
+        self._owner = owner
+        self._cfg = cfg
+        self._obs = obs
+        self._obs_kind = obs_kind
+        self._stats = {}
+
+    def __call__(self, x0=None, p=None, lbg=None, lbx=None, ubg=None, ubx=None, **_ignored):
+        cfg = self._cfg
+        nx = cfg.nx()
+        bs = self._owner._batch_solver(cfg)
+        if lbx is not None and ubx is not None and lbg is not None and ubg is not None:
+            bs.set_bounds(np.asarray(lbx, dtype=np.float64).reshape(-1), np.asarray(ubx, dtype=np.float64).reshape(-1),
+                          np.asarray(lbg, dtype=np.float64).reshape(-1), np.asarray(ubg, dtype=np.float64).reshape(-1))
+        pv = np.asarray(p, dtype=np.float64).reshape(-1)
+        if pv.size != 2 * nx:
+            raise ValueError("p must hold [x0; xs] (%d values)" % (2 * nx))
+        z0 = None if x0 is None else np.asarray(x0, dtype=np.float64).reshape(1, -1)
+        r = bs.solve_batch(pv[:nx].reshape(1, nx), pv[nx:].reshape(1, nx), self._obs, z0, multipliers=True)
+        st = int(r["status"][0])
+        self._stats = {"success": st == _abi.ST_SOLVED, "return_status": _RETURN_STATUS.get(st, "Unknown"),
+                       "iter_count": int(r["iters"][0]), "status_code": st, "kkt": r["kkt"][0].copy()}
+        self._owner.last_stats = self._stats
+        return {"x": DM(r["z"][0]), "f": DM(r["obj"][0]), "lam_g": DM(r["lam_g"][0]), "lam_x": DM(r["lam_x"][0]),
+                "lam_p": DM(np.zeros(2 * nx)), "g": DM(np.zeros(bs.ng))}
+
+    def stats(self):
+        return dict(self._stats)
+
+
+class MpcBase:
+    MODEL = _abi.MODEL_KIN
+
+    def __init__(self, params_file=PARAMS_FILE):
+        self.config = load_config(find_params_file(params_file))
+        mp = self.config["mpc_params"]
+        self.T_horizon = mp["horizon"]
+        self.T_S = mp["T_S"]
+        self.pre_time = mp["pre_time"]
+        self.T_L = mp["T_L"]
+        self.t_ratio = mp["t_ratio"]
+        self.is_variable_time = mp["is_variable_time"]
+        if self.is_variable_time == True:  # noqa: E712  (the reference compares with == True; 'Flase' is a str -> False)
+            t1 = np.arange(0, self.T_horizon * self.t_ratio, self.T_S, dtype=float)
+            t2 = np.arange(t1[-1] + self.T_L, t1[-1] + self.T_L + self.T_horizon * (1 - self.t_ratio), self.T_L)
+            self.N_p = len(t1) + len(t2)
+            self.t_vector = np.concatenate((t1, t2))
+        else:
+            self.t_vector = np.arange(0, self.T_horizon + self.T_S, self.T_S, dtype=float)
+            self.N_p = horizon_steps(self.T_horizon, self.T_S)
+        vp = self.config["vehicle_params"]
+        for key in ("Veh_l", "Veh_L", "Veh_m", "Veh_lf", "Veh_lr", "Veh_Iz"):
+            setattr(self, key, vp[key])
+        self.Veh_W = vp["Veh_W"] if "Veh_W" in vp else vp["Veh_w"]
+        tp = self.config["tire_params"]
+        self.aopt_f, self.aopt_r, self.Cf_0, self.Cr_0 = tp["aopt_f"], tp["aopt_r"], tp["Cf_0"], tp["Cr_0"]
+        self.Fymax_f = self.Cf_0 * self.aopt_f / 2
+        self.Fymax_r = self.Cr_0 * self.aopt_r / 2
+        dc = self.config["dynamics_constraints"]
+        self.vy_max, self.vy_min = dc["vy_max"], dc["vy_min"]
+        self.jerk_min, self.jerk_max = dc["jerk_min"], dc["jerk_max"]
+        self.df_dot_min = dc["df_dot_min"] * np.pi / 180
+        self.df_dot_max = dc["df_dot_max"] * np.pi / 180
+        kc = self.config["kinematics_constraints"]
+        self.vx_max, self.vx_min = kc["vx_max"], kc["vx_min"]
+        self.ax_max, self.ax_min = kc["ax_max"], kc["ax_min"]
+        self.df_max = kc["df_max"] * np.pi / 180
+        self.df_min = kc["df_min"] * np.pi / 180
+        self.Y_max, self.Y_min = kc["Y_max"], kc["Y_min"]
+        self.model_type = self.config["model_type"]
+        self.num_states = 6 if self.MODEL == _abi.MODEL_DYN else 4
+        self.num_controls = 2
+        self.last_stats = {}
+        self._solvers = {}
+        self.f = ModelFunction(self._make_cfg(0))
+
+    # ----- configuration of the HIP library from the YAML values ------------------------------------------
+    def _make_cfg(self, n_obs):
+        c = default_config(self.MODEL, int(self.N_p), float(self.T_S), int(n_obs))
+        c.u_lo[0], c.u_hi[0] = self.df_min, self.df_max
+        c.u_lo[1], c.u_hi[1] = self.ax_min, self.ax_max
+        c.x_lo[1], c.x_hi[1] = self.Y_min, self.Y_max
+        c.x_lo[3], c.x_hi[3] = self.vx_min, self.vx_max
+        c.du_lo[0], c.du_hi[0] = self.df_dot_min * self.T_S, self.df_dot_max * self.T_S
+        c.veh_l = self.Veh_l
+        c.ego_hl, c.ego_hw = self.Veh_L / 2, self.Veh_W / 2
+        c.veh_m, c.veh_lf, c.veh_lr, c.veh_Iz = self.Veh_m, self.Veh_lf, self.Veh_lr, self.Veh_Iz
+        c.Fymax_f, c.Fymax_r, c.aopt_f, c.aopt_r = self.Fymax_f, self.Fymax_r, self.aopt_f, self.aopt_r
+        if self.MODEL == _abi.MODEL_DYN:
+            c.x_lo[4], c.x_hi[4] = self.vy_min, self.vy_max
+            c.du_lo[1], c.du_hi[1] = self.jerk_min * self.T_S, self.jerk_max * self.T_S
+        return c
+
+    def _batch_solver(self, cfg):
+        key = (cfg.model, cfg.N, cfg.n_obs, cfg.obs_mode)
+        bs = self._solvers.get(key)
+        if bs is None:
+            bs = BatchSolver(cfg)
+            self._solvers[key] = bs
+        return bs
+
+    # ----- bounds in the reference's z / g order ---------------------------------------------------------------
+    def _box_lists(self):
+        lbx, ubx = [], []
+        for _ in range(self.N_p):
+            lbx += [self.df_min, self.ax_min]
+            ubx += [self.df_max, self.ax_max]
+        lo = [-np.inf, self.Y_min, -np.inf, self.vx_min]
+        hi = [np.inf, self.Y_max, np.inf, self.vx_max]
+        if self.MODEL == _abi.MODEL_DYN:
+            lo += [self.vy_min, -np.inf]
+            hi += [self.vy_max, np.inf]
+        for _ in range(self.N_p + 1):
+            lbx += lo
+            ubx += hi
+        return lbx, ubx

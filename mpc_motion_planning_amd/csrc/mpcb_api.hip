@@ -1,0 +1,532 @@
+// mpcb_api.hip — C ABI of libmpcbatch.so (include/mpcbatch.h) and the kernel launches.  gfx950 only.
+//
+// Host side: plain HIP runtime, one stream per handle, caller-owned buffers.  No torch, no oracle, no CPU
+// fallback: without a HIP device mpcb_create fails with MPCB_E_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "mpcb_kernel.h"
+
+#ifndef MPCB_WAVES_PER_SIMD
+#define MPCB_WAVES_PER_SIMD 1
+#endif
+
+namespace {
+
+constexpr double INF = std::numeric_limits<double>::infinity();
+thread_local std::string g_create_error;
+
+template <int NOBS>
+__global__ __launch_bounds__(64, MPCB_WAVES_PER_SIMD) void mpcb_kernel_kin(const MpcbKArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double mpcb_lds[];
+  mpcb_solve_kin<NOBS>(a, (int)blockIdx.x, mpcb_lds);
+}
+
+// closed-loop helper: plant step with the first control, warm-start shift, obstacle advance.
+// one thread per instance (tiny, HBM-bound, runs between two solves of the closed loop)
+//   main_cbf_kin_c_sim.py:16-26 (shift_movement), main_cbf_kin_c_sim_pre.py:106 (obstacle advance)
+__global__ void mpcb_advance_kin(int B, int N, int nz, int n_obs, double T, double veh_l, const double* __restrict__ z,
+                                 double* __restrict__ x0, double* __restrict__ z0, double* __restrict__ obs,
+                                 double* __restrict__ x_hist, double* __restrict__ u_hist, int step, int steps) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* zb = z + (size_t)b * nz;
+  double* xb = x0 + (size_t)b * 4;
+  const double d = zb[0], ac = zb[1];
+  const double x = xb[0], y = xb[1], phi = xb[2], v = xb[3];
+  // st = x0 + T f(x0, u[0])
+  const double nx0 = x + T * (v * cos(phi)), nx1 = y + T * (v * sin(phi)), nx2 = phi + T * (v * tan(d) / veh_l), nx3 = v + T * ac;
+  xb[0] = nx0; xb[1] = nx1; xb[2] = nx2; xb[3] = nx3;
+  if (u_hist) { u_hist[((size_t)b * steps + step) * 2] = d; u_hist[((size_t)b * steps + step) * 2 + 1] = ac; }
+  if (x_hist) { double* h = x_hist + ((size_t)b * (steps + 1) + step + 1) * 4; h[0] = nx0; h[1] = nx1; h[2] = nx2; h[3] = nx3; }
+  // u <- [u[1:]; u[-1]],  x_f <- [x_f[1:]; x_f[-1]]
+  double* w = z0 + (size_t)b * nz;
+  for (int i = 0; i < N; ++i) { int s = (i + 1 < N) ? i + 1 : N - 1; w[2 * i] = zb[2 * s]; w[2 * i + 1] = zb[2 * s + 1]; }
+  for (int i = 0; i <= N; ++i) { int s = (i + 1 <= N) ? i + 1 : N; for (int q = 0; q < 4; ++q) w[2 * N + 4 * i + q] = zb[2 * N + 4 * s + q]; }
+  // obstacles move one step with constant velocity and heading (Obs_prediction.py:27-30)
+  for (int j = 0; j < n_obs; ++j) {
+    double* o = obs + ((size_t)b * n_obs + j) * 6;
+    o[0] += o[3] * cos(o[2]) * T; o[1] += o[3] * sin(o[2]) * T;
+  }
+}
+
+// constant-velocity prediction of every obstacle over the horizon: [B, n_obs, 6] -> [B, n_obs, N+1, 6]
+__global__ void mpcb_predict_obs(int total, int N, double T, const double* __restrict__ obs, double* __restrict__ traj) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const double* o = obs + (size_t)i * 6;
+  double x = o[0], y = o[1];
+  const double sx = o[3] * cos(o[2]) * T, sy = o[3] * sin(o[2]) * T;
+  for (int k = 0; k <= N; ++k) {
+    double* t = traj + ((size_t)i * (N + 1) + k) * 6;
+    t[0] = x; t[1] = y; t[2] = o[2]; t[3] = o[3]; t[4] = o[4]; t[5] = o[5];
+    x += sx; y += sy;
+  }
+}
+
+}  // namespace
+
+struct mpcb_handle {
+  mpcb_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int nx = 4, nz = 0, ng = 0;
+  // scratch for the host-pointer entry
+  void* d_buf = nullptr; size_t d_cap = 0;
+  // timing
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  int launches = 0; double total_ms = 0, last_ms = 0;
+};
+
+namespace {
+
+int fail(mpcb_handle* h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  if (h) h->err = buf; else g_create_error = buf;
+  return code;
+}
+#define HIP_TRY(h, expr)                                                                         \
+  do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(h, MPCB_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+int nx_of(const mpcb_config& c) { return c.model == MPCB_MODEL_DYN ? 6 : 4; }
+int n_rate(const mpcb_config& c) {
+  int n = 0;
+  for (int i = 0; i < 2; ++i) if (std::isfinite(c.du_lo[i]) || std::isfinite(c.du_hi[i])) ++n;
+  return n;
+}
+
+int check_cfg(mpcb_handle* h, const mpcb_config* c) {
+  if (!c) return fail(h, MPCB_E_INVALID, "config is NULL");
+  if (c->struct_size != sizeof(mpcb_config))
+    return fail(h, MPCB_E_INVALID, "mpcb_config.struct_size = %u, this library expects %zu", c->struct_size, sizeof(mpcb_config));
+  if (c->model != MPCB_MODEL_KIN && c->model != MPCB_MODEL_DYN) return fail(h, MPCB_E_INVALID, "unknown model %d", c->model);
+  if (c->N < 1 || c->N > MPCB_N_MAX) return fail(h, MPCB_E_INVALID, "N = %d outside 1..%d", c->N, MPCB_N_MAX);
+  if (c->n_obs < 0 || c->n_obs > MPCB_NOBS_MAX) return fail(h, MPCB_E_INVALID, "n_obs = %d outside 0..%d", c->n_obs, MPCB_NOBS_MAX);
+  if (!(c->T > 0) || !(c->tol > 0) || c->max_iter < 0 || !(c->mu_init > 0)) return fail(h, MPCB_E_INVALID, "T, tol, mu_init must be > 0 and max_iter >= 0");
+  if (!(c->veh_l > 0)) return fail(h, MPCB_E_INVALID, "veh_l must be > 0");
+  for (int i = 0; i < 2; ++i) if (!(c->R[i] > 0)) return fail(h, MPCB_E_INVALID, "R must be positive");
+  if (c->model == MPCB_MODEL_DYN) return fail(h, MPCB_E_UNSUPPORTED, "the dynamic-bicycle kernel is not built yet (DESIGN.md, scope row f3)");
+  if (c->obs_mode == MPCB_OBS_DCBF && std::fabs(c->gamma - 1.0) > 1e-12)
+    return fail(h, MPCB_E_UNSUPPORTED, "discrete-CBF rows are implemented for gamma = 1 only (the reference's value, kin.py:235)");
+  if (c->obs_mode != MPCB_OBS_KEEPOUT && c->obs_mode != MPCB_OBS_DCBF) return fail(h, MPCB_E_INVALID, "unknown obs_mode %d", c->obs_mode);
+  if (c->mu_strategy != MPCB_MU_MONOTONE) return fail(h, MPCB_E_UNSUPPORTED, "only MPCB_MU_MONOTONE is implemented on the device");
+  // kinematic kernel: boxes on y and vx only, rate row on the steering angle only, rows not interleaved
+  if (std::isfinite(c->x_lo[0]) || std::isfinite(c->x_hi[0]) || std::isfinite(c->x_lo[2]) || std::isfinite(c->x_hi[2]))
+    return fail(h, MPCB_E_UNSUPPORTED, "kinematic kernel: state boxes are supported on y and vx (kin.py:97-105)");
+  if (std::isfinite(c->du_lo[1]) || std::isfinite(c->du_hi[1]))
+    return fail(h, MPCB_E_UNSUPPORTED, "kinematic kernel: rate rows are supported on the steering angle only (kin.py:216-217)");
+  if (c->rate_interleaved) return fail(h, MPCB_E_UNSUPPORTED, "kinematic kernel: rate rows form one block (kin.py:211-216)");
+  return MPCB_OK;
+}
+
+size_t lds_bytes(const mpcb_config& c, int nz) { return (size_t)mpcbk::layout_kin(c.N, nz).total * sizeof(double); }
+
+int launch_solve(mpcb_handle* h, const MpcbKArgs& a) {
+  const size_t lds = lds_bytes(h->cfg, h->nz);
+  if (lds > 160 * 1024) return fail(h, MPCB_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds);
+  if (a.B == 0) return MPCB_OK;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_TRY(h, hipEventCreate(&e0));
+  HIP_TRY(h, hipEventCreate(&e1));
+  HIP_TRY(h, hipEventRecord(e0, h->stream));
+  const dim3 grid(a.B), block(64);
+  const int n = h->cfg.n_obs;
+#define LAUNCH(NOBS)                                                                                           \
+  do {                                                                                                         \
+    if (lds > 48 * 1024)                                                                                       \
+      HIP_TRY(h, hipFuncSetAttribute((const void*)mpcb_kernel_kin<NOBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(mpcb_kernel_kin<NOBS>, grid, block, lds, h->stream, a);                                 \
+  } while (0)
+  if (n == 0) LAUNCH(0);
+  else if (n == 1) LAUNCH(1);
+  else if (n <= 3) LAUNCH(3);
+  else LAUNCH(8);
+#undef LAUNCH
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipEventRecord(e1, h->stream));
+  h->ev.emplace_back(e0, e1);
+  if (h->ev.size() > 8192) {   // bound the number of live events
+    HIP_TRY(h, hipEventSynchronize(h->ev.front().second));
+    float ms = 0; (void)hipEventElapsedTime(&ms, h->ev.front().first, h->ev.front().second);
+    h->total_ms += ms; h->last_ms = ms; ++h->launches;
+    (void)hipEventDestroy(h->ev.front().first); (void)hipEventDestroy(h->ev.front().second);
+    h->ev.erase(h->ev.begin());
+  }
+  return MPCB_OK;
+}
+
+int collect_timing(mpcb_handle* h) {
+  for (auto& p : h->ev) {
+    HIP_TRY(h, hipEventSynchronize(p.second));
+    float ms = 0;
+    HIP_TRY(h, hipEventElapsedTime(&ms, p.first, p.second));
+    h->total_ms += ms; h->last_ms = ms; ++h->launches;
+    (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+  }
+  h->ev.clear();
+  return MPCB_OK;
+}
+
+int ensure_scratch(mpcb_handle* h, size_t bytes) {
+  if (bytes <= h->d_cap) return MPCB_OK;
+  if (h->d_buf) { HIP_TRY(h, hipFree(h->d_buf)); h->d_buf = nullptr; h->d_cap = 0; }
+  HIP_TRY(h, hipMalloc(&h->d_buf, bytes));
+  h->d_cap = bytes;
+  return MPCB_OK;
+}
+
+struct Carve {
+  char* base; size_t off = 0;
+  template <class T> T* take(size_t n) { off = (off + 255) & ~size_t(255); T* p = (T*)(base + off); off += n * sizeof(T); return p; }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* mpcb_version(void) { return "mpcbatch 0.1 (gfx950, abi 1)"; }
+
+int mpcb_default_config(mpcb_config* cfg, int32_t model, int32_t N, double T) {
+  if (!cfg || (model != MPCB_MODEL_KIN && model != MPCB_MODEL_DYN)) return MPCB_E_INVALID;
+  mpcb_config c;
+  std::memset(&c, 0, sizeof c);
+  c.struct_size = sizeof(mpcb_config);
+  c.model = model; c.N = N; c.T = T; c.gamma = 1.0;
+  c.obs_mode = MPCB_OBS_KEEPOUT; c.max_iter = 100;                       // kin.py:252
+  c.mu_strategy = MPCB_MU_MONOTONE; c.init_rollout = 1;
+  const double rad = M_PI / 180.0;
+  for (int i = 0; i < MPCB_NX_MAX; ++i) { c.x_lo[i] = -INF; c.x_hi[i] = INF; }
+  // mpc_parameters.yaml: kinematics_constraints / dynamics_constraints / vehicle_params / tire_params
+  c.u_lo[0] = -35.0 * rad; c.u_hi[0] = 35.0 * rad; c.u_lo[1] = -3.0; c.u_hi[1] = 3.0;
+  c.x_lo[1] = -1.0; c.x_hi[1] = 5.0; c.x_lo[3] = 0.0; c.x_hi[3] = 40.0;
+  c.du_lo[0] = -5.0 * rad * T; c.du_hi[0] = 5.0 * rad * T; c.du_lo[1] = -INF; c.du_hi[1] = INF;
+  c.veh_l = 2.6; c.ego_hl = 4.8 / 2; c.ego_hw = 1.8 / 2; c.safe_disl = 1.0; c.safe_disw = 0.5;
+  c.veh_m = 1575.0; c.veh_lf = 1.2; c.veh_lr = 1.6; c.veh_Iz = 2875.0;
+  c.aopt_f = 0.3490658503988659; c.aopt_r = 0.19198621771937624;
+  c.Fymax_f = -50000.0 * c.aopt_f / 2; c.Fymax_r = -50000.0 * c.aopt_r / 2;
+  if (model == MPCB_MODEL_KIN) {
+    const double Q[4] = {1e1, 1e5, 3e5, 1e4};                             // kin.py:168-172
+    for (int i = 0; i < 4; ++i) c.Q[i] = Q[i];
+    c.R[0] = c.R[1] = 1e4; c.DR[0] = 1e5; c.DR[1] = 1e2;                  // kin.py:179-184
+    c.du0_cost = 1; c.obs_terminal = 0; c.obs_hmin = 0.0; c.rate_interleaved = 0;
+  } else {
+    const double Q[6] = {10, 1e5, 1e3, 1e3, 1, 1};                        // dyn.py:189-195
+    for (int i = 0; i < 6; ++i) c.Q[i] = Q[i];
+    c.R[0] = c.R[1] = 1e3; c.DR[0] = 5e3; c.DR[1] = 5e2;                  // dyn.py:204-209
+    c.x_lo[4] = -5.0; c.x_hi[4] = 5.0;
+    c.du_lo[1] = -3.0 * T; c.du_hi[1] = 1.5 * T;
+    c.du0_cost = 0; c.obs_terminal = 1; c.obs_hmin = 1.0; c.obs_sx_fixed = 4.0; c.obs_sy_fixed = 1.0; c.rate_interleaved = 1;
+  }
+  // IPOPT defaults; mu_init is raised from IPOPT's 0.1 because the roll-out start is already dynamics-feasible
+  c.tol = 1e-8; c.mu_init = 10.0; c.bound_push = 0.01; c.bound_frac = 0.01; c.bound_relax = 1e-8; c.max_gradient = 100.0;
+  *cfg = c;
+  return MPCB_OK;
+}
+
+int mpcb_dims(const mpcb_config* c, int32_t* nx, int32_t* nz, int32_t* ng) {
+  if (!c) return MPCB_E_INVALID;
+  const int n = nx_of(*c);
+  if (nx) *nx = n;
+  if (nz) *nz = 2 * c->N + n * (c->N + 1);
+  if (ng) *ng = n * (c->N + 1) + n_rate(*c) * (c->N - 1) + c->n_obs * (c->obs_terminal ? c->N + 1 : c->N);
+  return MPCB_OK;
+}
+
+int mpcb_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int mpcb_create(const mpcb_config* cfg, int32_t device, mpcb_handle** out) {
+  if (!out) return fail(nullptr, MPCB_E_INVALID, "out is NULL");
+  *out = nullptr;
+  int rc = check_cfg(nullptr, cfg);
+  if (rc != MPCB_OK) return rc;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) return fail(nullptr, MPCB_E_DEVICE, "no HIP device available (%s); libmpcbatch has no CPU path", e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+  if (device < 0 || device >= ndev) return fail(nullptr, MPCB_E_INVALID, "device %d outside 0..%d", device, ndev - 1);
+  mpcb_handle* h = new mpcb_handle();
+  h->cfg = *cfg; h->device = device;
+  int nx, nz, ng; mpcb_dims(cfg, &nx, &nz, &ng);
+  h->nx = nx; h->nz = nz; h->ng = ng;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return fail(nullptr, MPCB_E_DEVICE, "cannot create a stream on device %d", device);
+  }
+  *out = h;
+  return MPCB_OK;
+}
+
+int mpcb_destroy(mpcb_handle* h) {
+  if (!h) return MPCB_OK;
+  (void)hipSetDevice(h->device);
+  collect_timing(h);
+  if (h->d_buf) (void)hipFree(h->d_buf);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return MPCB_OK;
+}
+
+const char* mpcb_last_error(const mpcb_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mpcb_set_bounds(mpcb_handle* h, const double* lbx, const double* ubx, int32_t nz, const double* lbg, const double* ubg, int32_t ng) {
+  if (!h || !lbx || !ubx || !lbg || !ubg) return fail(h, MPCB_E_INVALID, "NULL argument");
+  mpcb_config c = h->cfg;
+  const int N = c.N, nx = h->nx;
+  if (nz != h->nz) return fail(h, MPCB_E_BOUNDS, "len(lbx) = %d, the NLP has %d variables", nz, h->nz);
+  // decision-vector boxes must repeat per stage (kin.py:90-105)
+  for (int k = 0; k < N; ++k) for (int i = 0; i < 2; ++i)
+    if (lbx[2 * k + i] != lbx[i] || ubx[2 * k + i] != ubx[i]) return fail(h, MPCB_E_BOUNDS, "control box differs at stage %d", k);
+  for (int k = 0; k <= N; ++k) for (int i = 0; i < nx; ++i)
+    if (lbx[2 * N + nx * k + i] != lbx[2 * N + i] || ubx[2 * N + nx * k + i] != ubx[2 * N + i]) return fail(h, MPCB_E_BOUNDS, "state box differs at node %d", k);
+  for (int i = 0; i < 2; ++i) { c.u_lo[i] = lbx[i]; c.u_hi[i] = ubx[i]; }
+  for (int i = 0; i < nx; ++i) { c.x_lo[i] = lbx[2 * N + i]; c.x_hi[i] = ubx[2 * N + i]; }
+  // rows: nx(N+1) equalities, rate rows, obstacle rows [hmin, inf)
+  const int n_obs_rows = c.n_obs * (c.obs_terminal ? N + 1 : N);
+  const int n_eq = nx * (N + 1);
+  const int rate_rows = ng - n_eq - n_obs_rows;
+  if (rate_rows < 0 || (rate_rows != 0 && rate_rows % (N - 1 > 0 ? N - 1 : 1) != 0) || (N > 1 && rate_rows / (N - 1) > 2))
+    return fail(h, MPCB_E_BOUNDS, "len(lbg) = %d does not match %d equality + k*(N-1) rate + %d obstacle rows", ng, n_eq, n_obs_rows);
+  const int nr = (N > 1) ? rate_rows / (N - 1) : 0;
+  std::vector<int> kind(ng, 0);   // 0 equality, 1.. rate comp+1, 3 obstacle
+  int r = 0;
+  if (!c.rate_interleaved) {
+    for (int i = 0; i < n_eq; ++i) kind[r++] = 0;
+    for (int k = 1; k < N; ++k) for (int q = 0; q < nr; ++q) kind[r++] = 1 + q;
+  } else {
+    for (int i = 0; i < nx; ++i) kind[r++] = 0;
+    for (int k = 0; k < N; ++k) { for (int i = 0; i < nx; ++i) kind[r++] = 0; if (k > 0) for (int q = 0; q < nr; ++q) kind[r++] = 1 + q; }
+  }
+  for (int i = 0; i < n_obs_rows; ++i) kind[r++] = 3;
+  double rl[2] = {-INF, -INF}, ru[2] = {INF, INF}; bool rset[2] = {false, false};
+  double ol = 0; bool oset = false;
+  for (int i = 0; i < ng; ++i) {
+    if (kind[i] == 0) {
+      if (lbg[i] != 0.0 || ubg[i] != 0.0) return fail(h, MPCB_E_BOUNDS, "row %d is a dynamics row of g but its bounds are [%g, %g], not [0, 0] (bounds and rows mis-aligned?)", i, lbg[i], ubg[i]);
+    } else if (kind[i] == 3) {
+      if (std::isfinite(ubg[i]) || !std::isfinite(lbg[i])) return fail(h, MPCB_E_BOUNDS, "row %d is an obstacle row but its bounds are [%g, %g]", i, lbg[i], ubg[i]);
+      if (oset && lbg[i] != ol) return fail(h, MPCB_E_BOUNDS, "obstacle rows have different lower bounds");
+      ol = lbg[i]; oset = true;
+    } else {
+      const int q = kind[i] - 1;
+      if (rset[q] && (lbg[i] != rl[q] || ubg[i] != ru[q])) return fail(h, MPCB_E_BOUNDS, "rate rows of control %d have different bounds", q);
+      if (lbg[i] == 0.0 && ubg[i] == 0.0) return fail(h, MPCB_E_BOUNDS, "row %d is a rate row of g but its bounds are [0, 0] (bounds and rows mis-aligned?)", i);
+      rl[q] = lbg[i]; ru[q] = ubg[i]; rset[q] = true;
+    }
+  }
+  // which controls carry rate rows: the configured ones, in order
+  int q = 0;
+  for (int i = 0; i < 2; ++i) {
+    const bool had = std::isfinite(h->cfg.du_lo[i]) || std::isfinite(h->cfg.du_hi[i]);
+    if (had) { if (q >= nr) return fail(h, MPCB_E_BOUNDS, "the NLP has rate rows on control %d but lbg has none", i); c.du_lo[i] = rl[q]; c.du_hi[i] = ru[q]; ++q; }
+  }
+  if (q != nr) return fail(h, MPCB_E_BOUNDS, "lbg carries %d rate rows per stage, the NLP has %d", nr, q);
+  if (oset) c.obs_hmin = ol;
+  mpcb_config saved = h->cfg;
+  int rc = check_cfg(h, &c);
+  if (rc != MPCB_OK) { h->cfg = saved; return rc; }
+  h->cfg = c;
+  return MPCB_OK;
+}
+
+int mpcb_solve_device(mpcb_handle* h, int32_t B, const double* d_x0, const double* d_xs, const double* d_obs, int32_t obs_kind,
+                      const double* d_z0, double* d_z, double* d_obj, int32_t* d_status, int32_t* d_iters, double* d_kkt,
+                      double* d_lam_g, double* d_lam_x, int32_t sync) {
+  if (!h) return MPCB_E_INVALID;
+  if (B < 0 || !d_x0 || !d_xs || !d_z) return fail(h, MPCB_E_INVALID, "B < 0 or a required pointer is NULL");
+  if (h->cfg.n_obs > 0 && !d_obs) return fail(h, MPCB_E_INVALID, "n_obs = %d but obs is NULL", h->cfg.n_obs);
+  if (obs_kind != MPCB_OBSIN_STATIC && obs_kind != MPCB_OBSIN_PREDICTED) return fail(h, MPCB_E_INVALID, "unknown obs_kind %d", obs_kind);
+  HIP_TRY(h, hipSetDevice(h->device));
+  MpcbKArgs a;
+  a.cfg = h->cfg; a.B = B; a.nz = h->nz; a.ng = h->ng; a.obs_kind = obs_kind;
+  a.want_mult = (d_lam_g || d_lam_x) ? 1 : 0; a.trace_instance = -1; a.trace = nullptr;
+  a.x0 = d_x0; a.xs = d_xs; a.obs = d_obs; a.z0 = d_z0;
+  a.z = d_z; a.obj = d_obj; a.kkt = d_kkt; a.lam_g = d_lam_g; a.lam_x = d_lam_x; a.status = d_status; a.iters = d_iters;
+  int rc = launch_solve(h, a);
+  if (rc != MPCB_OK) return rc;
+  if (sync) HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPCB_OK;
+}
+
+int mpcb_solve(mpcb_handle* h, int32_t B, const double* x0, const double* xs, const double* obs, int32_t obs_kind, const double* z0,
+               double* z, double* obj, int32_t* status, int32_t* iters, double* kkt, double* lam_g, double* lam_x) {
+  if (!h) return MPCB_E_INVALID;
+  if (B < 0 || !x0 || !xs || !z) return fail(h, MPCB_E_INVALID, "B < 0 or a required pointer is NULL");
+  if (h->cfg.n_obs > 0 && !obs) return fail(h, MPCB_E_INVALID, "n_obs = %d but obs is NULL", h->cfg.n_obs);
+  if (B == 0) return MPCB_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int nx = h->nx, nz = h->nz, ng = h->ng, N = h->cfg.N;
+  const size_t n_obs_d = (size_t)B * h->cfg.n_obs * 6 * (obs_kind == MPCB_OBSIN_PREDICTED ? N + 1 : 1);
+  const size_t need = ((size_t)B * (2 * nx + 2 * nz + 1 + 4 + (lam_g ? ng : 0) + (lam_x ? nz : 0)) + n_obs_d) * 8 + (size_t)B * 8 + 4096 * 4;
+  int rc = ensure_scratch(h, need);
+  if (rc != MPCB_OK) return rc;
+  Carve cv{(char*)h->d_buf};
+  double* d_x0 = cv.take<double>((size_t)B * nx);
+  double* d_xs = cv.take<double>((size_t)B * nx);
+  double* d_obs = n_obs_d ? cv.take<double>(n_obs_d) : nullptr;
+  double* d_z0 = z0 ? cv.take<double>((size_t)B * nz) : nullptr;
+  double* d_z = cv.take<double>((size_t)B * nz);
+  double* d_obj = cv.take<double>(B);
+  double* d_kkt = cv.take<double>((size_t)B * 4);
+  double* d_lg = lam_g ? cv.take<double>((size_t)B * ng) : nullptr;
+  double* d_lx = lam_x ? cv.take<double>((size_t)B * nz) : nullptr;
+  int32_t* d_st = cv.take<int32_t>(B);
+  int32_t* d_it = cv.take<int32_t>(B);
+  hipStream_t s = h->stream;
+  HIP_TRY(h, hipMemcpyAsync(d_x0, x0, (size_t)B * nx * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(d_xs, xs, (size_t)B * nx * 8, hipMemcpyHostToDevice, s));
+  if (d_obs) HIP_TRY(h, hipMemcpyAsync(d_obs, obs, n_obs_d * 8, hipMemcpyHostToDevice, s));
+  if (d_z0) HIP_TRY(h, hipMemcpyAsync(d_z0, z0, (size_t)B * nz * 8, hipMemcpyHostToDevice, s));
+  rc = mpcb_solve_device(h, B, d_x0, d_xs, d_obs, obs_kind, d_z0, d_z, d_obj, d_st, d_it, d_kkt, d_lg, d_lx, 0);
+  if (rc != MPCB_OK) return rc;
+  HIP_TRY(h, hipMemcpyAsync(z, d_z, (size_t)B * nz * 8, hipMemcpyDeviceToHost, s));
+  if (obj) HIP_TRY(h, hipMemcpyAsync(obj, d_obj, (size_t)B * 8, hipMemcpyDeviceToHost, s));
+  if (kkt) HIP_TRY(h, hipMemcpyAsync(kkt, d_kkt, (size_t)B * 4 * 8, hipMemcpyDeviceToHost, s));
+  if (status) HIP_TRY(h, hipMemcpyAsync(status, d_st, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+  if (iters) HIP_TRY(h, hipMemcpyAsync(iters, d_it, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+  if (lam_g) HIP_TRY(h, hipMemcpyAsync(lam_g, d_lg, (size_t)B * ng * 8, hipMemcpyDeviceToHost, s));
+  if (lam_x) HIP_TRY(h, hipMemcpyAsync(lam_x, d_lx, (size_t)B * nz * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  return MPCB_OK;
+}
+
+int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps, const double* x0, const double* xs, double* obs_state, int32_t predict,
+                     double* x_hist, double* u_hist, int32_t* status_hist, int32_t* iters_hist) {
+  if (!h) return MPCB_E_INVALID;
+  if (B < 0 || steps < 0 || !x0 || !xs) return fail(h, MPCB_E_INVALID, "B < 0, steps < 0 or a required pointer is NULL");
+  if (h->cfg.n_obs > 0 && !obs_state) return fail(h, MPCB_E_INVALID, "n_obs = %d but obs_state is NULL", h->cfg.n_obs);
+  if (B == 0 || steps == 0) return MPCB_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int nx = h->nx, nz = h->nz, N = h->cfg.N, no = h->cfg.n_obs;
+  const size_t n_traj = predict ? (size_t)B * no * (N + 1) * 6 : 0;
+  const size_t need = ((size_t)B * (2 * nx + 2 * nz + no * 6 + (size_t)(steps + 1) * nx + (size_t)steps * 2) + n_traj) * 8 +
+                      (size_t)B * steps * 8 + 8192 * 4;
+  int rc = ensure_scratch(h, need);
+  if (rc != MPCB_OK) return rc;
+  Carve cv{(char*)h->d_buf};
+  double* d_x0 = cv.take<double>((size_t)B * nx);
+  double* d_xs = cv.take<double>((size_t)B * nx);
+  double* d_obs = no ? cv.take<double>((size_t)B * no * 6) : nullptr;
+  double* d_traj = n_traj ? cv.take<double>(n_traj) : nullptr;
+  double* d_z0 = cv.take<double>((size_t)B * nz);
+  double* d_z = cv.take<double>((size_t)B * nz);
+  double* d_xh = cv.take<double>((size_t)B * (steps + 1) * nx);
+  double* d_uh = cv.take<double>((size_t)B * steps * 2);
+  int32_t* d_st = cv.take<int32_t>((size_t)B * steps);
+  int32_t* d_it = cv.take<int32_t>((size_t)B * steps);
+  hipStream_t s = h->stream;
+  HIP_TRY(h, hipMemcpyAsync(d_x0, x0, (size_t)B * nx * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(d_xs, xs, (size_t)B * nx * 8, hipMemcpyHostToDevice, s));
+  if (d_obs) HIP_TRY(h, hipMemcpyAsync(d_obs, obs_state, (size_t)B * no * 6 * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemsetAsync(d_z0, 0, (size_t)B * nz * 8, s));                  // u0 = 0, next_states = 0 (main_cbf_kin_c_sim.py:47-50)
+  HIP_TRY(h, hipMemcpy2DAsync(d_xh, (size_t)(steps + 1) * nx * 8, d_x0, (size_t)nx * 8, (size_t)nx * 8, B, hipMemcpyDeviceToDevice, s));
+  // the per-step status / iteration columns are strided: solve writes into a compact column, then scatter
+  int32_t* d_stc = cv.take<int32_t>(B);
+  int32_t* d_itc = cv.take<int32_t>(B);
+  for (int t = 0; t < steps; ++t) {
+    const double* obs_in = d_obs; int kind = MPCB_OBSIN_STATIC;
+    if (predict && no) {
+      const int total = B * no;
+      hipLaunchKernelGGL(mpcb_predict_obs, dim3((total + 255) / 256), dim3(256), 0, s, total, N, h->cfg.T, d_obs, d_traj);
+      obs_in = d_traj; kind = MPCB_OBSIN_PREDICTED;
+    }
+    rc = mpcb_solve_device(h, B, d_x0, d_xs, obs_in, kind, d_z0, d_z, nullptr, d_stc, d_itc, nullptr, nullptr, nullptr, 0);
+    if (rc != MPCB_OK) return rc;
+    HIP_TRY(h, hipMemcpy2DAsync(d_st + t, (size_t)steps * 4, d_stc, 4, 4, B, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(h, hipMemcpy2DAsync(d_it + t, (size_t)steps * 4, d_itc, 4, 4, B, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(mpcb_advance_kin, dim3((B + 127) / 128), dim3(128), 0, s, B, N, nz, no, h->cfg.T, h->cfg.veh_l, d_z, d_x0, d_z0,
+                       d_obs, d_xh, d_uh, t, steps);
+    HIP_TRY(h, hipGetLastError());
+  }
+  if (x_hist) HIP_TRY(h, hipMemcpyAsync(x_hist, d_xh, (size_t)B * (steps + 1) * nx * 8, hipMemcpyDeviceToHost, s));
+  if (u_hist) HIP_TRY(h, hipMemcpyAsync(u_hist, d_uh, (size_t)B * steps * 2 * 8, hipMemcpyDeviceToHost, s));
+  if (status_hist) HIP_TRY(h, hipMemcpyAsync(status_hist, d_st, (size_t)B * steps * 4, hipMemcpyDeviceToHost, s));
+  if (iters_hist) HIP_TRY(h, hipMemcpyAsync(iters_hist, d_it, (size_t)B * steps * 4, hipMemcpyDeviceToHost, s));
+  if (d_obs) HIP_TRY(h, hipMemcpyAsync(obs_state, d_obs, (size_t)B * no * 6 * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  return MPCB_OK;
+}
+
+int mpcb_dev_alloc(mpcb_handle* h, uint64_t bytes, void** dptr) {
+  if (!h || !dptr) return MPCB_E_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMalloc(dptr, bytes ? bytes : 8));
+  return MPCB_OK;
+}
+int mpcb_dev_free(mpcb_handle* h, void* dptr) {
+  if (!h) return MPCB_E_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipFree(dptr));
+  return MPCB_OK;
+}
+int mpcb_dev_upload(mpcb_handle* h, void* dptr, const void* src, uint64_t bytes) {
+  if (!h || !dptr || !src) return MPCB_E_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpyAsync(dptr, src, bytes, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPCB_OK;
+}
+int mpcb_dev_download(mpcb_handle* h, void* dst, const void* dptr, uint64_t bytes) {
+  if (!h || !dptr || !dst) return MPCB_E_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpyAsync(dst, dptr, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPCB_OK;
+}
+int mpcb_sync(mpcb_handle* h) {
+  if (!h) return MPCB_E_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPCB_OK;
+}
+
+int mpcb_timing(mpcb_handle* h, int32_t reset, int32_t* launches, double* total_ms, double* last_ms) {
+  if (!h) return MPCB_E_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc = collect_timing(h);
+  if (rc != MPCB_OK) return rc;
+  if (launches) *launches = h->launches;
+  if (total_ms) *total_ms = h->total_ms;
+  if (last_ms) *last_ms = h->last_ms;
+  if (reset) { h->launches = 0; h->total_ms = 0; h->last_ms = 0; }
+  return MPCB_OK;
+}
+
+int mpcb_model_rhs(const mpcb_config* c, const double* x, const double* u, double* xdot) {
+  if (!c || !x || !u || !xdot) return MPCB_E_INVALID;
+  if (c->model == MPCB_MODEL_KIN) {                      // kin.py:153-156
+    xdot[0] = x[3] * std::cos(x[2]);
+    xdot[1] = x[3] * std::sin(x[2]);
+    xdot[2] = x[3] * std::tan(u[0]) / c->veh_l;
+    xdot[3] = u[1];
+    return MPCB_OK;
+  }
+  if (c->model == MPCB_MODEL_DYN) {                      // dyn.py:156-170
+    const double phi = x[2], vx = x[3], vy = x[4], r = x[5], df = u[0], ax = u[1];
+    const double af = df - (vy + c->veh_lf * r) / vx, ar = -(vy - c->veh_lr * r) / vx;
+    const double Cf = c->Fymax_f * 2 * c->aopt_f / (c->aopt_f * c->aopt_f + af * af);
+    const double Cr = c->Fymax_r * 2 * c->aopt_r / (c->aopt_r * c->aopt_r + ar * ar);
+    const double Fcf = -Cf * af, Fcr = -Cr * ar;
+    xdot[0] = vx * std::cos(phi) - vy * std::sin(phi);
+    xdot[1] = vx * std::sin(phi) + vy * std::cos(phi);
+    xdot[2] = r;
+    xdot[3] = ax + r * vy;
+    xdot[4] = -r * vx + 2.0 / c->veh_m * (Fcf * std::cos(df) + Fcr);
+    xdot[5] = 2.0 / c->veh_Iz * (c->veh_lf * Fcf - c->veh_lr * Fcr);
+    return MPCB_OK;
+  }
+  return MPCB_E_INVALID;
+}
+
+}  // extern "C"

@@ -59,7 +59,7 @@ enum KinEnt {
 struct Layout {
   int ld, ent, Pst, pst, Kst, kff, W, q, M, m, dX, dU, filt, zbuf, total;
 };
-MPCB_DEV Layout layout_kin(int N, int nz) {
+MPCB_HD Layout layout_kin(int N, int nz) {
   Layout L;
   const int N1 = N + 1, NA = 6, NW = 8, NX = 4;
   L.ld = N1 | 1;

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #define MPCB_DEV __device__ __forceinline__
 #define MPCB_DEVFN __device__
+#define MPCB_HD __host__ __device__ inline
 
 namespace wv {
 MPCB_DEV int lane() { return (int)threadIdx.x; }
@@ -49,6 +50,7 @@ MPCB_DEV bool all(bool p) { return __all(p) != 0; }
 #include <cmath>
 #define MPCB_DEV inline
 #define MPCB_DEVFN
+#define MPCB_HD inline
 
 namespace wv {
 struct Emu {

@@ -1,0 +1,170 @@
+"""BatchSolver — thin Python front of the C ABI (include/mpcbatch.h) for batches of MPC instances.
+
+This is the batched extension of the reference's per-step  `solver = ca.nlpsol(...)` / `res = solver(x0=, p=, ...)`
+pair (CasaDi_MPC_Optimize_Multishoot/MPC_CBF_optimize_kin.py:251-254, main_cbf_kin_c_sim.py:100): one handle per
+NLP structure, one call per batch of parameter vectors and obstacle sets.  numpy + ctypes only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import MpcbConfig, dptr, iptr
+from ._lib import lib, check
+
+
+def default_config(model=_abi.MODEL_KIN, N=30, T=0.1, n_obs=0):
+    cfg = MpcbConfig()
+    check(lib().mpcb_default_config(C.byref(cfg), model, N, T))
+    cfg.n_obs = n_obs
+    return cfg
+
+
+def dims(cfg):
+    nx, nz, ng = C.c_int32(), C.c_int32(), C.c_int32()
+    check(lib().mpcb_dims(C.byref(cfg), C.byref(nx), C.byref(nz), C.byref(ng)))
+    return nx.value, nz.value, ng.value
+
+
+def device_count():
+    return lib().mpcb_device_count()
+
+
+def model_rhs(cfg, x, u):
+    """f(x,u) of the configured model (the reference's `mpc_solver.f`, kin.py:159)."""
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
+    u = np.ascontiguousarray(np.asarray(u, dtype=np.float64).reshape(-1))
+    out = np.zeros(cfg.nx())
+    check(lib().mpcb_model_rhs(C.byref(cfg), dptr(x), dptr(u), dptr(out)))
+    return out
+
+
+class DeviceArray:
+    """A caller-owned device buffer (row-major, float64 or int32)."""
+
+    def __init__(self, solver, shape, dtype=np.float64):
+        self.solver = solver
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(lib().mpcb_dev_alloc(solver._h, self.nbytes, C.byref(p)), solver._h)
+        self.ptr = p
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.size * a.itemsize == self.nbytes, "size mismatch"
+        check(lib().mpcb_dev_upload(self.solver._h, self.ptr, a.ctypes.data_as(C.c_void_p), self.nbytes), self.solver._h)
+        return self
+
+    def download(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(lib().mpcb_dev_download(self.solver._h, out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes), self.solver._h)
+        return out
+
+    def free(self):
+        if self.ptr is not None and self.solver._h:
+            lib().mpcb_dev_free(self.solver._h, self.ptr)
+        self.ptr = None
+
+
+class BatchSolver:
+    def __init__(self, cfg, device=0):
+        self.cfg = cfg.copy()
+        self._h = C.c_void_p()
+        rc = lib().mpcb_create(C.byref(self.cfg), device, C.byref(self._h))
+        if rc != 0:
+            check(rc, None)
+        self.nx, self.nz, self.ng = dims(self.cfg)
+        self.N = self.cfg.N
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().mpcb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------------
+    def set_bounds(self, lbx, ubx, lbg, ubg):
+        """Adopt (and validate) the four lists `initialize_constraints` returns (kin.py:84-134)."""
+        lbx = np.ascontiguousarray(lbx, dtype=np.float64); ubx = np.ascontiguousarray(ubx, dtype=np.float64)
+        lbg = np.ascontiguousarray(lbg, dtype=np.float64); ubg = np.ascontiguousarray(ubg, dtype=np.float64)
+        if lbx.shape != ubx.shape or lbg.shape != ubg.shape:
+            raise ValueError("lbx/ubx or lbg/ubg lengths differ")
+        check(lib().mpcb_set_bounds(self._h, dptr(lbx), dptr(ubx), lbx.size, dptr(lbg), dptr(ubg), lbg.size), self._h)
+
+    def _obs(self, obs, B):
+        if self.cfg.n_obs == 0:
+            return None, _abi.OBSIN_STATIC
+        obs = np.ascontiguousarray(obs, dtype=np.float64)
+        n = self.cfg.n_obs
+        if obs.size == B * n * 6:
+            return obs.reshape(B, n, 6), _abi.OBSIN_STATIC
+        if obs.size == B * n * (self.N + 1) * 6:
+            return obs.reshape(B, n, self.N + 1, 6), _abi.OBSIN_PREDICTED
+        raise ValueError("obs has %d values; expected [B,%d,6] or [B,%d,%d,6]" % (obs.size, n, n, self.N + 1))
+
+    def solve_batch(self, x0, xs, obs=None, z0=None, multipliers=False):
+        """x0, xs [B,nx]; obs [B,n_obs,6] | [B,n_obs,N+1,6]; z0 [B,nz] | None  ->  dict(z, obj, status, iters, kkt[, lam_g, lam_x])"""
+        x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, dtype=np.float64)))
+        xs = np.ascontiguousarray(np.atleast_2d(np.asarray(xs, dtype=np.float64)))
+        B = x0.shape[0]
+        if x0.shape != (B, self.nx) or xs.shape != (B, self.nx):
+            raise ValueError("x0 and xs must be [B,%d]" % self.nx)
+        obs, kind = self._obs(obs, B)
+        if z0 is not None:
+            z0 = np.ascontiguousarray(np.asarray(z0, dtype=np.float64).reshape(B, self.nz))
+        z = np.empty((B, self.nz)); obj = np.empty(B); st = np.empty(B, np.int32); it = np.empty(B, np.int32)
+        kkt = np.empty((B, 4))
+        lam_g = np.empty((B, self.ng)) if multipliers else None
+        lam_x = np.empty((B, self.nz)) if multipliers else None
+        check(lib().mpcb_solve(self._h, B, dptr(x0), dptr(xs), dptr(obs), kind, dptr(z0), dptr(z), dptr(obj), iptr(st),
+                               iptr(it), dptr(kkt), dptr(lam_g), dptr(lam_x)), self._h)
+        out = dict(z=z, obj=obj, status=st, iters=it, kkt=kkt)
+        if multipliers:
+            out["lam_g"] = lam_g; out["lam_x"] = lam_x
+        return out
+
+    def closed_loop(self, x0, xs, obs_state=None, steps=80, predict=False):
+        """Receding-horizon loop on the device (main_cbf_kin_c_sim.py:87-123).  Returns dict(x_hist, u_hist, status, iters, obs_state)."""
+        x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, dtype=np.float64)))
+        xs = np.ascontiguousarray(np.atleast_2d(np.asarray(xs, dtype=np.float64)))
+        B = x0.shape[0]
+        ob = None
+        if self.cfg.n_obs:
+            ob = np.array(obs_state, dtype=np.float64).reshape(B, self.cfg.n_obs, 6).copy()
+        xh = np.empty((B, steps + 1, self.nx)); uh = np.empty((B, steps, 2))
+        st = np.empty((B, steps), np.int32); it = np.empty((B, steps), np.int32)
+        check(lib().mpcb_closed_loop(self._h, B, steps, dptr(x0), dptr(xs), dptr(ob), 1 if predict else 0, dptr(xh), dptr(uh),
+                                     iptr(st), iptr(it)), self._h)
+        return dict(x_hist=xh, u_hist=uh, status=st, iters=it, obs_state=ob)
+
+    # ----- device-resident path (bench.py, multi-GPU plumbing) -------------------------------------------
+    def device_array(self, shape, dtype=np.float64):
+        return DeviceArray(self, shape, dtype)
+
+    def solve_device(self, B, d_x0, d_xs, d_obs, obs_kind, d_z0, d_z, d_obj=None, d_status=None, d_iters=None, d_kkt=None,
+                     d_lam_g=None, d_lam_x=None, sync=False):
+        """Raw device pointers (ints / c_void_p / DeviceArray).  Asynchronous on the handle's stream unless sync."""
+        def p(v):
+            if v is None:
+                return None
+            if isinstance(v, DeviceArray):
+                return v.ptr
+            return C.c_void_p(int(v)) if not isinstance(v, C.c_void_p) else v
+        check(lib().mpcb_solve_device(self._h, B, p(d_x0), p(d_xs), p(d_obs), obs_kind, p(d_z0), p(d_z), p(d_obj), p(d_status),
+                                      p(d_iters), p(d_kkt), p(d_lam_g), p(d_lam_x), 1 if sync else 0), self._h)
+
+    def sync(self):
+        check(lib().mpcb_sync(self._h), self._h)
+
+    def timing(self, reset=False):
+        n = C.c_int32(); tot = C.c_double(); last = C.c_double()
+        check(lib().mpcb_timing(self._h, 1 if reset else 0, C.byref(n), C.byref(tot), C.byref(last)), self._h)
+        return dict(launches=n.value, total_ms=tot.value, last_ms=last.value)

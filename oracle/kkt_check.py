@@ -1,0 +1,126 @@
+"""Independent KKT certificate for the reference's NLP.  TEST INFRASTRUCTURE ONLY (numpy).
+
+The NLP is written here a second time, straight from the reference's text and in its flat ordering
+(z = [vec(U); vec(X)], g rows in the order they are appended), with NO hand-written derivative: gradients and the
+constraint Jacobian come from complex-step differentiation of these functions.  A solver result (z, lam_g, lam_x)
+is then judged by the first-order optimality conditions in IPOPT's sign convention
+    grad f(z) + J_g(z)^T lam_g + lam_x = 0,   lbg <= g(z) <= ubg,   lbx <= z <= ubx,
+    lam > 0 only at an upper bound, lam < 0 only at a lower bound.
+This depends on neither the oracle's nor the kernel's algebra, so it certifies both.
+
+References (CMOM = CasaDi_MPC_Optimize_Multishoot/):
+  model           CMOM/MPC_CBF_optimize_kin.py:153-156
+  objective       CMOM/MPC_CBF_optimize_kin.py:168-205
+  rows            CMOM/MPC_CBF_optimize_kin.py:190-191,207-216,236-248 ; _kin_pre.py:236-253
+  bounds          CMOM/MPC_CBF_optimize_kin.py:84-134
+"""
+import numpy as np
+
+
+class KinNlp:
+    """The kinematic NLP for one instance.  obs: (n_obs,6) static or (n_obs,N+1,6) predicted; rows [x,y,th,v,l,w]."""
+
+    def __init__(self, N, T, x0, xs, obs=None, Q=(1e1, 1e5, 3e5, 1e4), R=(1e4, 1e4), DR=(1e5, 1e2), veh_l=2.6,
+                 veh_L=4.8, veh_W=1.8, safe_disl=1.0, safe_disw=0.5, df_lim=35 * np.pi / 180, a_lim=3.0, y_lim=(-1.0, 5.0),
+                 v_lim=(0.0, 40.0), ddf_lim=5 * np.pi / 180, obs_mode="keepout", gamma=1.0, u_last=(0.0, 0.0)):
+        self.N, self.T = N, T
+        self.x0 = np.asarray(x0, float).reshape(4); self.xs = np.asarray(xs, float).reshape(4)
+        self.Q, self.R, self.DR = np.asarray(Q, float), np.asarray(R, float), np.asarray(DR, float)
+        self.veh_l = veh_l
+        self.u_last = np.asarray(u_last, float)
+        self.obs_mode, self.gamma = obs_mode, gamma
+        if obs is None or np.size(obs) == 0:
+            self.obs = np.zeros((0, N + 1, 6))
+        else:
+            obs = np.asarray(obs, float)
+            if obs.ndim == 2:
+                obs = np.repeat(obs[:, None, :], N + 1, axis=1)
+            self.obs = obs
+        self.n_obs = self.obs.shape[0]
+        self.sx = veh_L / 2 + self.obs[:, :, 4] / 2 + safe_disl      # kin.py:242
+        self.sy = veh_W / 2 + self.obs[:, :, 5] / 2 + safe_disw      # kin.py:243
+        self.nz = 2 * N + 4 * (N + 1)
+        self.ng = 4 * (N + 1) + (N - 1) + N * self.n_obs
+        # bounds (kin.py:84-134)
+        self.lbx = np.concatenate([np.tile([-df_lim, -a_lim], N), np.tile([-np.inf, y_lim[0], -np.inf, v_lim[0]], N + 1)])
+        self.ubx = np.concatenate([np.tile([df_lim, a_lim], N), np.tile([np.inf, y_lim[1], np.inf, v_lim[1]], N + 1)])
+        self.lbg = np.concatenate([np.zeros(4 * (N + 1)), np.full(N - 1, -ddf_lim * T), np.zeros(N * self.n_obs)])
+        self.ubg = np.concatenate([np.zeros(4 * (N + 1)), np.full(N - 1, ddf_lim * T), np.full(N * self.n_obs, np.inf)])
+
+    def split(self, z):
+        N = self.N
+        U = z[:2 * N].reshape(N, 2)          # U[i] = [df_i, ax_i]
+        X = z[2 * N:].reshape(N + 1, 4)      # X[k] = [x, y, phi, vx]
+        return U, X
+
+    def rhs(self, X, U):
+        return np.stack([X[:, 3] * np.cos(X[:, 2]), X[:, 3] * np.sin(X[:, 2]), X[:, 3] * np.tan(U[:, 0]) / self.veh_l, U[:, 1]], axis=1)
+
+    def f(self, z):
+        U, X = self.split(z)
+        e = X[:-1] - self.xs
+        Up = np.vstack([self.u_last.astype(z.dtype)[None, :], U[:-1]])
+        return (e * e * self.Q).sum() + (U * U * self.R).sum() + ((U - Up) ** 2 * self.DR).sum()
+
+    def h(self, X, k, step):
+        o = self.obs[:, step, :]
+        return (X[k, 0] - o[:, 0]) ** 2 / self.sx[:, step] ** 2 + (X[k, 1] - o[:, 1]) ** 2 / self.sy[:, step] ** 2 - 1.0
+
+    def g(self, z):
+        U, X = self.split(z)
+        N = self.N
+        rows = [X[0] - self.x0]
+        nxt = X[:-1] + self.T * self.rhs(X[:-1], U)
+        rows.append((X[1:] - nxt).reshape(-1))
+        rows.append(U[1:, 0] - U[:-1, 0])
+        for i in range(N):
+            if self.n_obs == 0:
+                break
+            hi = self.h(X, i, i)
+            if self.obs_mode == "keepout":
+                rows.append(hi)                                           # kin.py:247
+            else:
+                rows.append(self.gamma * hi + (self.h(X, i + 1, i) - hi))   # kin.py:245-248
+        return np.concatenate([np.asarray(r).reshape(-1) for r in rows])
+
+    # complex-step derivatives ------------------------------------------------------------------------------------
+    def grad_f(self, z, h=1e-30):
+        g = np.empty(self.nz)
+        zc = z.astype(complex)
+        for i in range(self.nz):
+            zc[i] += 1j * h
+            g[i] = self.f(zc).imag / h
+            zc[i] = z[i]
+        return g
+
+    def jac_g(self, z, h=1e-30):
+        J = np.empty((self.ng, self.nz))
+        zc = z.astype(complex)
+        for i in range(self.nz):
+            zc[i] += 1j * h
+            J[:, i] = self.g(zc).imag / h
+            zc[i] = z[i]
+        return J
+
+
+def certificate(nlp, z, lam_g, lam_x, act_tol=1e-6):
+    """Returns dict of unscaled KKT residuals."""
+    z = np.asarray(z, float); lam_g = np.asarray(lam_g, float); lam_x = np.asarray(lam_x, float)
+    gv = nlp.g(z)
+    stat = nlp.grad_f(z) + nlp.jac_g(z).T @ lam_g + lam_x
+    viol_g = np.maximum(0, np.maximum(nlp.lbg - gv, gv - nlp.ubg)).max()
+    viol_x = np.maximum(0, np.maximum(nlp.lbx - z, z - nlp.ubx)).max()
+
+    def compl(lam, v, lo, hi):
+        eq = lo == hi
+        dist_hi = np.where(np.isfinite(hi), hi - v, np.inf)
+        dist_lo = np.where(np.isfinite(lo), v - lo, np.inf)
+        c = np.where(lam > 0, lam * np.maximum(dist_hi, 0), -lam * np.maximum(dist_lo, 0))
+        c = np.where(eq, 0.0, c)
+        wrong_sign = np.where(~eq & (lam > 0) & ~np.isfinite(hi), lam, 0.0) + np.where(~eq & (lam < 0) & ~np.isfinite(lo), -lam, 0.0)
+        return np.nan_to_num(c, posinf=0.0).max(), wrong_sign.max()
+
+    cg, sg = compl(lam_g, gv, nlp.lbg, nlp.ubg)
+    cx, sx = compl(lam_x, z, nlp.lbx, nlp.ubx)
+    return dict(stationarity=np.abs(stat).max(), feas_g=viol_g, feas_x=viol_x, compl=max(cg, cx), sign=max(sg, sx),
+                f=float(nlp.f(z)), lam_scale=max(1.0, np.abs(lam_g).max(), np.abs(lam_x).max()))

@@ -1,0 +1,51 @@
+// tests/emu/wave_emu.cpp — TEST INFRASTRUCTURE ONLY.
+//
+// Steps the device source mpc_motion_planning_amd/csrc/mpcb_kernel.h on the CPU: every lane of the wavefront is a
+// host thread, cross-lane primitives (mpcb_wave.h, MPCB_WAVE_EMU branch) go through a barrier.  It exists so that
+// the kernel's logic can be checked against the oracle in the `-m "not gpu"` suite and while developing without
+// a GPU.  It is NOT part of libmpcbatch.so, is never loaded by the mpc_motion_planning_amd package and is far
+// too slow to be a fallback (64 OS threads per instance).
+#define MPCB_WAVE_EMU 1
+#include "../../mpc_motion_planning_amd/csrc/mpcb_kernel.h"
+
+#include <thread>
+#include <vector>
+
+namespace wv {
+thread_local int t_lane = 0;
+thread_local Emu* t_emu = nullptr;
+}
+
+template <int NOBS>
+static void run_instance(const MpcbKArgs& a, int b) {
+  using namespace mpcbk;
+  Layout L = layout_kin(a.cfg.N, a.nz);
+  std::vector<double> lds(L.total + 64, 0.0);
+  std::barrier<> bar(64);
+  wv::Emu emu; emu.bar = &bar;
+  std::vector<std::thread> th;
+  for (int l = 0; l < 64; ++l)
+    th.emplace_back([&, l]() { wv::t_lane = l; wv::t_emu = &emu; mpcb_solve_kin<NOBS>(a, b, lds.data()); });
+  for (auto& t : th) t.join();
+}
+
+extern "C" int mpcb_emu_solve(const mpcb_config* cfg, int32_t B, const double* x0, const double* xs, const double* obs,
+                              int32_t obs_kind, const double* z0, double* z, double* obj, int32_t* status, int32_t* iters,
+                              double* kkt, double* lam_g, double* lam_x, double* trace, int32_t trace_instance) {
+  if (!cfg || cfg->model != MPCB_MODEL_KIN) return MPCB_E_UNSUPPORTED;
+  MpcbKArgs a;
+  a.cfg = *cfg; a.B = B; a.obs_kind = obs_kind; a.want_mult = (lam_g || lam_x) ? 1 : 0; a.trace_instance = trace_instance;
+  a.nz = 2 * cfg->N + 4 * (cfg->N + 1);
+  a.ng = 4 * (cfg->N + 1) + ((cfg->du_lo[0] > -1e300 || cfg->du_hi[0] < 1e300) ? cfg->N - 1 : 0) +
+         cfg->n_obs * (cfg->obs_terminal ? cfg->N + 1 : cfg->N);
+  a.x0 = x0; a.xs = xs; a.obs = obs; a.z0 = z0; a.z = z; a.obj = obj; a.kkt = kkt; a.lam_g = lam_g; a.lam_x = lam_x;
+  a.status = status; a.iters = iters; a.trace = trace;
+  for (int b = 0; b < B; ++b) {
+    if (cfg->n_obs == 0) run_instance<0>(a, b);
+    else if (cfg->n_obs == 1) run_instance<1>(a, b);
+    else if (cfg->n_obs <= 3) run_instance<3>(a, b);
+    else if (cfg->n_obs <= 8) run_instance<8>(a, b);
+    else return MPCB_E_UNSUPPORTED;
+  }
+  return MPCB_OK;
+}
