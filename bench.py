@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path: MPC solves/sec, kinematic bicycle N=30 + obstacle rows (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the solver over one batch per GPU: BASELINE config C2 — kinematic bicycle, N=30, T=0.1 s,
+1 static obstacle [50,3.5,0,8,4.8,1.8], set-point [400,3.5,0,30], batch 4096 random feasible-at-node-0 initial states
+per GPU (seeded), cold start z0 = 0 (as the reference's first step, main_cbf_kin_c_sim.py:47-50).
+Inputs are resident in HBM before the timed region.  Instances are independent, so ranks shard the batch with no
+data-path collective; for N > 1 every step ends with ONE RCCL all-gather of the converged trajectories
+(torch.distributed, backend nccl = RCCL) so that every rank holds all of them — it is inside the timed region.
+"scaling" is weak: per-GPU batch fixed.
+
+value = instances that reached the KKT tolerance (status 0) on all ranks * K / max-over-ranks wall time.  Instances
+that end with another status (the random scenes include unavoidable collisions, i.e. infeasible NLPs) are counted
+in config.failed_per_step and are NOT part of value, though their time is.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (spec)
+
+
+def algorithmic_bytes_per_solve(nx, nz, n_obs_values):
+    # 8*(2*nx + nz_in + obs_in + nz_out) + 16   (status i32 + iters i32 + obj f64)
+    return 8 * (2 * nx + nz + n_obs_values + nz) + 16
+
+
+def cpu_baseline(cfg, x0, xs, obs, min_seconds=2.0):
+    """The CPU oracle (oracle/mpc_oracle.cpp, same NLP, same algorithm, OpenMP over the batch) timed on this box's
+    host cores on a bounded sample of the same workload.  Reported next to the GPU number; CasADi+IPOPT cannot be
+    timed (not installed here nor on the GPU box, no network: SURVEY.md §0 F2)."""
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    n = min(len(x0), 2048)
+    t0 = time.perf_counter(); reps = 0; solved = 0
+    while True:
+        r = oracle.solve(cfg, x0[:n], xs[:n], obs[:n], threads=cores, want_multipliers=False)
+        solved += int((r["status"] == 0).sum()); reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds or reps >= 8:
+            break
+    return {"value": solved / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": "%d x first %d instances of the step's batch, OpenMP over instances, %.1f s wall (%.0f core-s)" % (reps, n, dt, dt * cores),
+            "note": "own FP64 C++ restatement of the NLP + IPOPT-style solver; CasADi+IPOPT baseline unavailable (casadi not installed)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus %d needs the torch.distributed launcher (one process per GPU)" % args.gpus)
+
+    from mpc_motion_planning_amd import scenes, _abi
+    from mpc_motion_planning_amd.solver import BatchSolver, default_config, dims
+
+    dist = None; torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    B = args.batch
+    cfg = default_config(model=_abi.MODEL_KIN, N=30, T=0.1, n_obs=1)
+    nx, nz, ng = dims(cfg)
+    x0, xs, obs = scenes.sample_c2(B, seed=1000 + rank)
+    bs = BatchSolver(cfg, device=local_rank)
+    d_x0 = bs.device_array((B, nx)).upload(x0)
+    d_xs = bs.device_array((B, nx)).upload(xs)
+    d_obs = bs.device_array((B, 1, 6)).upload(obs)
+    d_obj = bs.device_array((B,)); d_kkt = bs.device_array((B, 4))
+    d_st = bs.device_array((B,), np.int32); d_it = bs.device_array((B,), np.int32)
+    if world > 1:   # z lives in a torch tensor so that RCCL can gather it; the solver only sees its raw pointer
+        z_local = torch.empty((B, nz), dtype=torch.float64, device="cuda")
+        z_all = torch.empty((world * B, nz), dtype=torch.float64, device="cuda")
+        z_ptr = z_local.data_ptr()
+    else:
+        d_z = bs.device_array((B, nz)); z_ptr = d_z
+
+    def step():
+        bs.solve_device(B, d_x0, d_xs, d_obs, _abi.OBSIN_STATIC, None, z_ptr, d_obj, d_st, d_it, d_kkt)
+        if world > 1:
+            bs.sync()                                   # the solve runs on the library's own stream
+            dist.all_gather_into_tensor(z_all, z_local)
+
+    def fence():
+        bs.sync()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    bs.timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    tm = bs.timing()
+
+    status = d_st.download(); iters = d_it.download()
+    solved = int((status == 0).sum())
+    if world > 1:
+        t = torch.tensor([dt, float(solved), float(tm["total_ms"])], dtype=torch.float64, device="cuda")
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max = float(tmax[0]); solved_all = int(round(float(tsum[1])))
+    else:
+        dt_max = dt; solved_all = solved
+
+    if rank == 0:
+        kernel_ms = tm["total_ms"] / max(1, tm["launches"])
+        abytes = algorithmic_bytes_per_solve(nx, nz, 6) * B
+        achieved = abytes / (kernel_ms * 1e-3) / 1e9
+        it_ok = iters[status == 0]
+        flops = 56e3 * float(iters.sum())       # ~56 kflop per interior-point iteration at N=30 (kin)
+        out = {
+            "metric": "mpc_solves_per_sec", "value": solved_all * args.steps / dt_max, "unit": "solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: kinematic bicycle + 1 static CBF/keep-out obstacle row set (MPC_CBF_optimize_kin), N=30, "
+                                   "T=0.1, batch %d random x0 per GPU, cold start z0=0" % B,
+                       "batch_per_gpu": B, "solved_per_step": solved_all, "failed_per_step": world * B - solved_all,
+                       "iters_mean_solved": float(it_ok.mean()) if len(it_ok) else None, "iters_max": int(iters.max()),
+                       "tol": cfg.tol, "collective": "rccl all_gather of z per step" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "mpcb_kernel_kin<1>", "kernel_ms_avg": kernel_ms,
+                         "algorithmic_bytes_per_launch": abytes,
+                         "note": "compulsory I/O is 3072 B/solve; the solve is LDS-resident, bound by FP64 VALU issue and the serial "
+                                 "Riccati chain, not by HBM (SURVEY.md F10, DESIGN.md §5)"},
+            "roofline_fp64": {"bound": "fp64_valu", "achieved": flops / (kernel_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": flops / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                              "model": "56 kflop x interior-point iterations summed over the batch"},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, x0, xs, obs)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -115,7 +115,8 @@ def certificate(nlp, z, lam_g, lam_x, act_tol=1e-6):
         eq = lo == hi
         dist_hi = np.where(np.isfinite(hi), hi - v, np.inf)
         dist_lo = np.where(np.isfinite(lo), v - lo, np.inf)
-        c = np.where(lam > 0, lam * np.maximum(dist_hi, 0), -lam * np.maximum(dist_lo, 0))
+        with np.errstate(invalid="ignore"):
+            c = np.where(lam > 0, lam * np.maximum(dist_hi, 0), -lam * np.maximum(dist_lo, 0))
         c = np.where(eq, 0.0, c)
         wrong_sign = np.where(~eq & (lam > 0) & ~np.isfinite(hi), lam, 0.0) + np.where(~eq & (lam < 0) & ~np.isfinite(lo), -lam, 0.0)
         return np.nan_to_num(c, posinf=0.0).max(), wrong_sign.max()

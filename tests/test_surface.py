@@ -1,0 +1,70 @@
+"""The drop-in Python surface (no GPU needed: construction, bounds lists, shift, model function)."""
+import numpy as np
+import pytest
+
+from mpc_motion_planning_amd import MPC_CBF_optimize_kin, MPC_CBF_optimize_kin_pre, MPC_CBF_optimize_dyn, shift, shift_movement
+from mpc_motion_planning_amd.Obs_prediction import obs_prediction
+
+
+def test_kin_constructor_and_bounds_lists():
+    m = MPC_CBF_optimize_kin.MPC_optimize()
+    assert (m.N_p, m.T_S, m.num_states, m.num_controls) == (30, 0.1, 4, 2)
+    assert len(m.t_vector) == 31
+    assert m.df_max == pytest.approx(35 * np.pi / 180) and m.df_dot_max == pytest.approx(5 * np.pi / 180)
+    assert m.Fymax_f == pytest.approx(-50000 * 0.3490658503988659 / 2)
+    obs = np.array([[50, 3.5, 0, 8, 4.8, 1.8]])
+    lbg, ubg, lbx, ubx = m.initialize_constraints(obs)
+    # facts of the reference's lists (MPC_CBF_optimize_kin.py:84-134)
+    assert all(isinstance(v, list) for v in (lbg, ubg, lbx, ubx))
+    assert len(lbx) == len(ubx) == 184 and len(lbg) == len(ubg) == 124 + 29 + 30
+    assert lbx[:2] == [m.df_min, m.ax_min] and ubx[:2] == [m.df_max, m.ax_max]
+    assert lbx[60:64] == [-np.inf, -1, -np.inf, 0.0] and ubx[60:64] == [np.inf, 5, np.inf, 40.0]
+    assert lbg[:124] == [0.0] * 124 and ubg[:124] == [0.0] * 124
+    assert lbg[124] == pytest.approx(-8.7266e-3, rel=1e-4) and ubg[152] == pytest.approx(8.7266e-3, rel=1e-4)
+    assert lbg[153:] == [0.0] * 30 and all(np.isinf(ubg[153:]))
+    lbg3, _, _, _ = m.initialize_constraints(np.tile(obs, (3, 1)))
+    assert len(lbg3) == 243
+
+
+def test_kin_pre_and_dyn_bounds():
+    m = MPC_CBF_optimize_kin_pre.MPC_optimize()
+    tr = obs_prediction([np.array([[50, 3.5, 0, 10, 4.8, 1.8]])], m.T_S, m.N_p)
+    lbg, ubg, lbx, ubx = m.initialize_constraints(tr)
+    assert len(lbg) == 183 and len(lbx) == 184
+    d = MPC_CBF_optimize_dyn.MPC_optimize()                # the reference raises KeyError('Veh_w') here (dyn.py:45)
+    assert d.num_states == 6
+    lbg, ubg, lbx, ubx = d.initialize_constraints()
+    N = d.N_p
+    assert len(lbx) == 2 * N + 6 * (N + 1) and len(lbg) == 6 * (N + 1) + 2 * (N - 1) + (N + 1)
+    assert lbg[6:18] == [0.0] * 12 and lbg[18] == pytest.approx(-5 * np.pi / 180 * 0.1)   # rate rows follow stage 1 (aligned with g)
+
+
+def test_shift_matches_reference_semantics():
+    m = MPC_CBF_optimize_kin.MPC_optimize()
+    N = m.N_p
+    u = np.arange(2 * N, dtype=float).reshape(N, 2) * 1e-3
+    xf = np.arange(4 * (N + 1), dtype=float).reshape(N + 1, 4)
+    x0 = np.array([0, 3, 0.1, 15.0]).reshape(-1, 1)
+    t, st, u_end, xf2 = shift(0.1, 0.5, x0, u, xf, m.f)
+    assert shift is shift_movement and t == pytest.approx(0.6)
+    f = np.array([15 * np.cos(0.1), 15 * np.sin(0.1), 15 * np.tan(u[0, 0]) / 2.6, u[0, 1]])
+    assert st.shape == (4, 1) and np.allclose(st[:, 0], x0[:, 0] + 0.1 * f, atol=1e-15)
+    assert np.array_equal(u_end[:-1], u[1:]) and np.array_equal(u_end[-1], u[-1])
+    assert np.array_equal(xf2[:-1], xf[1:]) and np.array_equal(xf2[-1], xf[-1])
+
+
+def test_model_function_returns_dm():
+    m = MPC_CBF_optimize_kin.MPC_optimize()
+    v = m.f(np.array([0, 3, 0, 15.0]).reshape(-1, 1), np.array([0.0, 1.0]))
+    assert v.full().shape == (4, 1) and np.allclose(v.full()[:, 0], [15, 0, 0, 1])
+
+
+def test_sharding_bounds():
+    from mpc_motion_planning_amd.sharding import shard_bounds
+    for B in (0, 1, 7, 4096, 65537):
+        for W in (1, 2, 3, 8):
+            cuts = [shard_bounds(B, W, r) for r in range(W)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == B
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(W - 1))
+            sizes = [hi - lo for lo, hi in cuts]
+            assert max(sizes) - min(sizes) <= 1
