@@ -42,7 +42,11 @@ def cpu_baseline(cfg, x0, xs, obs, min_seconds=2.0):
     host cores on a bounded sample of the same workload.  Reported next to the GPU number; CasADi+IPOPT cannot be
     timed (not installed here nor on the GPU box, no network: SURVEY.md §0 F2)."""
     from oracle import oracle
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("MPCB_CPU_THREADS", "16"))))   # the 1-GPU box's CPU share is 16 cores
     n = min(len(x0), 2048)
     t0 = time.perf_counter(); reps = 0; solved = 0
     while True:
