@@ -10,7 +10,7 @@
 //   * lane k owns shooting node k (k = 0..N <= 63): X_k, U_k, the costate of the dynamics row that defines X_k,
 //     and the slacks/duals of every inequality row attached to node k.  Model evaluation, row residuals,
 //     condensing of the inequality rows into the stage Hessian/gradient, step-length rules and all
-//     line-search trial evaluations are lane-parallel; scalars are combined with wave reductions.
+//     line-search trial evaluations are lane-parallel; scalars are combined with fused wave reductions.
 //   * the KKT system is solved by a Riccati sweep over the stages with the state augmented by the previous
 //     control: stage block (nx+2+2)^2 = 8x8 = 64 entries = ONE ENTRY PER LANE for the kinematic model.
 //     Stage data are staged in LDS as [entry][node] (node fastest, odd leading dimension) so that the
@@ -25,7 +25,7 @@
 
 #ifdef MPCB_WAVE_EMU
 #include <cmath>
-using std::cos; using std::sin; using std::tan; using std::log; using std::fabs; using std::pow; using std::fmin; using std::fmax;
+using std::log; using std::fabs; using std::sqrt; using std::pow; using std::fmin; using std::fmax; using std::rint; using std::fma;
 using std::isfinite;
 #endif
 
@@ -38,9 +38,6 @@ struct MpcbKArgs {
   double* trace;   // optional: [max_iter + 1][8] log of instance trace_instance (debug / parity tests)
 };
 
-// ---------------------------------------------------------------------------------------------------------
-// LDS layout (doubles).  ld = (N+1)|1: odd leading dimension of the [entry][node] tables.
-// ---------------------------------------------------------------------------------------------------------
 namespace mpcbk {
 
 constexpr int NU = 2;
@@ -56,12 +53,13 @@ enum KinEnt {
   KIN_NENT
 };
 
+// LDS layout (doubles).  ld = (N+1)|1: odd leading dimension of the [entry][node] tables.
 struct Layout {
-  int ld, ent, Pst, pst, Kst, kff, W, q, M, m, dX, dU, filt, zbuf, total;
+  int ld, ent, Pst, pst, Kst, kff, W, q, filt, zbuf, total;
 };
 MPCB_HD Layout layout_kin(int N, int nz) {
   Layout L;
-  const int N1 = N + 1, NA = 6, NW = 8, NX = 4;
+  const int N1 = N + 1, NA = 6, NW = 8;
   L.ld = N1 | 1;
   int o = 0;
   L.ent = o; o += KIN_NENT * L.ld;
@@ -69,14 +67,10 @@ MPCB_HD Layout layout_kin(int N, int nz) {
   L.pst = o; o += N1 * NA;
   L.Kst = o; o += N1 * 2 * NA;
   L.kff = o; o += N1 * 2;
-  L.W = o; o += NW * NA;
-  L.q = o; o += NW;
-  L.M = o; o += NW * NW;
-  L.m = o; o += NW;
-  L.dX = o; o += N1 * NX;
-  L.dU = o; o += N1 * NU;
+  L.W = o; o += 2 * NW * NA;         // double-buffered W^T (one buffer per stage parity: no WAR hazard between stages)
+  L.q = o; o += 2 * NW;
   L.filt = o; o += 2 * FILTER_MAX;
-  L.zbuf = L.Pst;                 // staging of z rows aliases the Riccati storage (used before / after the loop)
+  L.zbuf = L.Pst;                   // staging of z rows aliases the Riccati storage (used before / after the loop)
   (void)nz;
   L.total = o;
   return L;
@@ -86,8 +80,8 @@ struct Bnd { double L, U; bool hasL, hasU, on; };
 MPCB_DEV Bnd mk_bnd(double L, double U, double relax) {
   Bnd q;
   q.hasL = L > -1e300; q.hasU = U < 1e300; q.on = q.hasL || q.hasU;
-  q.L = q.hasL ? L - relax * fmax(1.0, fabs(L)) : L;
-  q.U = q.hasU ? U + relax * fmax(1.0, fabs(U)) : U;
+  q.L = wv::uni(q.hasL ? L - relax * fmax(1.0, fabs(L)) : L);
+  q.U = wv::uni(q.hasU ? U + relax * fmax(1.0, fabs(U)) : U);
   return q;
 }
 MPCB_DEV double push_in(const Bnd& q, double v, double k1, double k2) {
@@ -99,17 +93,45 @@ MPCB_DEV double push_in(const Bnd& q, double v, double k1, double k2) {
   else if (q.hasU) v = fmin(v, q.U - k1 * fmax(1.0, fabs(q.U)));
   return v;
 }
-// Sigma = vL/(s-L) + vU/(U-s) and the barrier gradient coefficient gb = mu/(s-L) - mu/(U-s) - Sigma r
-MPCB_DEV void sig_gb(const Bnd& q, double s, double vL, double vU, double r, double mu, double& sig, double& gb) {
-  sig = 0; gb = 0;
-  if (q.hasL) { double d = s - q.L; sig += vL / d; gb += mu / d; }
-  if (q.hasU) { double d = q.U - s; sig += vU / d; gb -= mu / d; }
-  gb -= sig * r;
+
+// One inequality item in registers: duals and the cached reciprocals of the two distances to the bounds.
+// For a variable box the slack IS the variable; for a general row `s` is its own iterate.
+struct Item { double vL, vU, iL, iU; };
+MPCB_DEV void item_recip(const Bnd& q, double s, Item& it) {
+  it.iL = q.hasL ? wv::rcp(s - q.L) : 0.0;
+  it.iU = q.hasU ? wv::rcp(q.U - s) : 0.0;
 }
-MPCB_DEV double dual_y(const Bnd& q, double vL, double vU) { return (q.hasL ? vL : 0.0) - (q.hasU ? vU : 0.0); }
+MPCB_DEV double item_y(const Bnd& q, const Item& it) { return (q.hasL ? it.vL : 0.0) - (q.hasU ? it.vU : 0.0); }
+// Sigma = vL/(s-L) + vU/(U-s);  gb = mu/(s-L) - mu/(U-s) - Sigma r
+MPCB_DEV void item_sig_gb(const Item& it, double r, double mu, double& sig, double& gb) {
+  sig = it.vL * it.iL + it.vU * it.iU;
+  gb = mu * (it.iL - it.iU) - sig * r;
+}
+MPCB_DEV void item_dv(const Bnd& q, const Item& it, double ds, double mu, double& dvL, double& dvU) {
+  dvL = q.hasL ? mu * it.iL - it.vL - it.vL * it.iL * ds : 0.0;
+  dvU = q.hasU ? mu * it.iU - it.vU + it.vU * it.iU * ds : 0.0;
+}
+
+// sin and cos for |x| up to ~1e5 (headings and steering angles): Cody-Waite reduction by pi/2 in two pieces and the
+// fdlibm kernel polynomials on [-pi/4, pi/4]; < 1 ulp there.  Much smaller than the library's Payne-Hanek path.
+MPCB_DEV void sincos_b(double x, double& s, double& c) {
+  const double kq = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-kq, 1.57079632673412561417e+00, x);
+  r = fma(-kq, 6.07710050650619224932e-11, r);
+  const double z = r * r;
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                        -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                        2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double sk = fma(r * z, ps, r);
+  const double ck = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int q = ((int)kq) & 3;
+  s = (q == 0) ? sk : (q == 1) ? ck : (q == 2) ? -sk : -ck;
+  c = (q == 0) ? ck : (q == 1) ? -sk : (q == 2) ? -ck : sk;
+}
 
 // IPOPT constants (Waechter & Biegler 2006 / IPOPT option defaults)
-constexpr double K_EPS = 10.0, K_MU = 0.2, TH_MU = 1.5, TAU_MIN = 0.99;
+constexpr double K_EPS = 10.0, K_MU = 0.2, TAU_MIN = 0.99;
 constexpr double G_THETA = 1e-5, G_PHI = 1e-8, DELTA = 1.0, S_THETA = 1.1, S_PHI = 2.3, ETA_PHI = 1e-8, G_ALPHA = 0.05;
 constexpr double K_SIGMA = 1e10, S_MAX = 100.0;
 constexpr double DW_FIRST = 1e-4, DW_MIN = 1e-20, DW_MAX = 1e40, KW_MINUS = 1.0 / 3.0, KW_PLUS = 8.0, KW_PLUS_FIRST = 100.0;
@@ -122,7 +144,7 @@ constexpr double DW_FIRST = 1e-4, DW_MIN = 1e-20, DW_MAX = 1e40, KW_MINUS = 1.0 
 template <int NOBS>
 MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   using namespace mpcbk;
-  constexpr int NX = 4, NA = 6, NW = 8;
+  constexpr int NX = 4, NA = 6, NW = 8, NOB = NOBS > 0 ? NOBS : 1;
   const mpcb_config& c = a.cfg;
   const int N = c.N, lane = wv::lane(), k = lane;
   const int nz = a.nz, nobs = c.n_obs;
@@ -144,7 +166,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   if (c.obs_mode == MPCB_OBS_KEEPOUT) { obs_node = k <= last_row; ostep = k; }
   else { obs_node = k >= 1 && k - 1 <= last_row; ostep = k - 1; }
   obs_node = obs_node && isnode;
-  double ox[NOBS > 0 ? NOBS : 1], oy[NOBS > 0 ? NOBS : 1], ix2[NOBS > 0 ? NOBS : 1], iy2[NOBS > 0 ? NOBS : 1];
+  double ox[NOB], oy[NOB], ix2[NOB], iy2[NOB];
 #pragma unroll
   for (int j = 0; j < NOBS; ++j) {
     ox[j] = 0; oy[j] = 0; ix2[j] = 0; iy2[j] = 0;
@@ -192,8 +214,8 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         g = fmax(g, fabs(gu));
       }
     }
-    g = wv::max(g);
-    os = (g > c.max_gradient) ? c.max_gradient / g : 1.0;
+    g = wv::uni(wv::max(g));
+    os = wv::uni((g > c.max_gradient) ? c.max_gradient / g : 1.0);
   }
   // pin node 0
   if (k == 0) {
@@ -225,103 +247,99 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   const bool rr_on = xcost && qR.on;
   const bool ro_node = xnode && obs_node;
 
-  // model evaluation at (X, U): F = X + T f, nontrivial Jacobian entries
-  double F[NX], a02, a03, a12, a13, a23, b20, sp, cp, td, sec2;
-  auto model = [&]() {
-    sp = sin(X[2]); cp = cos(X[2]); td = tan(U[0]); sec2 = 1.0 + td * td;
-    const double v = X[3];
-    F[0] = X[0] + T * v * cp; F[1] = X[1] + T * v * sp; F[2] = X[2] + T * v * td * il; F[3] = X[3] + T * U[1];
-    a02 = -T * v * sp; a03 = T * cp; a12 = T * v * cp; a13 = T * sp; a23 = T * td * il; b20 = T * v * sec2 * il;
+  // model quantities at (X, U): sin/cos of the heading, tan and sec^2 of the steering angle
+  double sp, cp, td, sec2;
+  auto trig = [&](double phi, double df, double& s_, double& c_, double& t_, double& e_) {
+    sincos_b(phi, s_, c_);
+    double sd, cd; sincos_b(df, sd, cd);
+    const double icd = wv::rcp(cd);
+    t_ = sd * icd; e_ = icd * icd;
   };
 
-  // optional roll-out of X from x0 with the guessed controls
+  // optional roll-out of X from x0 with the guessed (clipped) controls
   if (c.init_rollout) {
     U[0] = hasu ? fmin(fmax(U[0], c.u_lo[0]), c.u_hi[0]) : 0.0;
     U[1] = hasu ? fmin(fmax(U[1], c.u_lo[1]), c.u_hi[1]) : 0.0;
+    double sd, cd; sincos_b(U[0], sd, cd);
+    const double tdr = sd * wv::rcp(cd);
+#pragma clang loop unroll(disable)
     for (int s = 0; s < N; ++s) {
-      model();
-#pragma unroll
-      for (int i = 0; i < NX; ++i) { double nx_ = wv::shfl(F[i], s); if (k == s + 1) X[i] = nx_; }
+      double sps, cps; sincos_b(X[2], sps, cps);
+      const double v = X[3];
+      const double F0 = X[0] + T * (v * cps), F1 = X[1] + T * (v * sps), F2 = X[2] + T * (v * tdr * il), F3 = X[3] + T * U[1];
+      const double n0 = wv::bcast(F0, s), n1 = wv::bcast(F1, s), n2 = wv::bcast(F2, s), n3 = wv::bcast(F3, s);
+      if (k == s + 1) { X[0] = n0; X[1] = n1; X[2] = n2; X[3] = n3; }
     }
   }
 
   // push the start inside the (relaxed) boxes; duals = 1
-  double zU0L = 1, zU0U = 1, zU1L = 1, zU1U = 1, zYL = 1, zYU = 1, zVL = 1, zVU = 1;
+  Item iU0{1, 1, 0, 0}, iU1{1, 1, 0, 0}, iY{1, 1, 0, 0}, iV{1, 1, 0, 0}, iR{1, 1, 0, 0};
   if (bu0_on) U[0] = push_in(qU0, U[0], c.bound_push, c.bound_frac);
   if (bu1_on) U[1] = push_in(qU1, U[1], c.bound_push, c.bound_frac);
   if (by_on) X[1] = push_in(qY, X[1], c.bound_push, c.bound_frac);
   if (bv_on) X[3] = push_in(qV, X[3], c.bound_push, c.bound_frac);
   // general rows: slack = row value at the pushed start, pushed inside its own bounds
   double Up0 = wv::shfl(U[0], k - 1), Up1 = wv::shfl(U[1], k - 1);   // U_{k-1}
-  double sR = 0, vRL = 1, vRU = 1, rR = 0;
+  double sR = 0, rR = 0;
   if (rr_on) sR = push_in(qR, U[0] - Up0, c.bound_push, c.bound_frac);
-  double sO[NOBS > 0 ? NOBS : 1], vO[NOBS > 0 ? NOBS : 1], rO[NOBS > 0 ? NOBS : 1], gO0[NOBS > 0 ? NOBS : 1], gO1[NOBS > 0 ? NOBS : 1];
-  bool ro_on[NOBS > 0 ? NOBS : 1];
+  double sO[NOB], vO[NOB], iO[NOB], rO[NOB], gO0[NOB], gO1[NOB];
+  bool ro_on[NOB];
 #pragma unroll
   for (int j = 0; j < NOBS; ++j) {
     ro_on[j] = ro_node && j < nobs;
     sO[j] = ro_on[j] ? push_in(qO, hval(j, X[0], X[1]), c.bound_push, c.bound_frac) : 1.0;
-    vO[j] = 1.0; rO[j] = 0; gO0[j] = 0; gO1[j] = 0;
+    vO[j] = 1.0; rO[j] = 0; gO0[j] = 0; gO1[j] = 0; iO[j] = 0;
   }
+  auto recips = [&]() {
+    if (bu0_on) item_recip(qU0, U[0], iU0);
+    if (bu1_on) item_recip(qU1, U[1], iU1);
+    if (by_on) item_recip(qY, X[1], iY);
+    if (bv_on) item_recip(qV, X[3], iV);
+    if (rr_on) item_recip(qR, sR, iR);
+#pragma unroll
+    for (int j = 0; j < NOBS; ++j) if (ro_on[j]) iO[j] = wv::rcp(sO[j] - qO.L);
+  };
 
   double mu = c.mu_init, tau = fmax(TAU_MIN, 1.0 - mu);
   double dfc[NX] = {0, 0, 0, 0};
-  double theta = 0, fval = 0;
+  double theta = 0, fval = 0, logsum = 0;   // sum |constraint residual|, unscaled objective, sum of log(distance to bound)
 
-  // unscaled objective of a trajectory given in node lanes (kin.py:195-205)
-  auto objective = [&](const double* Xa, const double* Ua, double up0, double up1) {
-    double f = 0;
-    if (hasu) {
+  // per-lane pieces of an evaluation at (Xa, Ua): defects, row residuals, theta/f/log partial sums.
+  // Returns false in a lane whose slack or box distance is not positive.
+  auto eval_lane = [&](const double* Xa, const double* Ua, double sRa, const double* sOa, double s_, double c_, double t_,
+                       double* dfa, double& rRa, double* rOa, double& up0, double& up1, double& th, double& fl, double& prod) {
+    bool ok = true;
+    const double v = Xa[3];
+    const double Ft[NX] = {Xa[0] + T * (v * c_), Xa[1] + T * (v * s_), Xa[2] + T * (v * t_ * il), Xa[3] + T * Ua[1]};
+    th = 0; fl = 0; prod = 1.0;
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { double e = Xa[i] - xs[i]; f += c.Q[i] * e * e; }
-      f += c.R[0] * Ua[0] * Ua[0] + c.R[1] * Ua[1] * Ua[1];
+    for (int i = 0; i < NX; ++i) { const double xn = wv::shfl(Xa[i], k + 1); dfa[i] = hasu ? Ft[i] - xn : 0.0; th += fabs(dfa[i]); }
+    up0 = wv::shfl(Ua[0], k - 1); up1 = wv::shfl(Ua[1], k - 1);
+    auto bar = [&](const Bnd& q, double s) {
+      if (q.hasL) { const double d = s - q.L; ok = ok && (d > 0); prod *= d; }
+      if (q.hasU) { const double d = q.U - s; ok = ok && (d > 0); prod *= d; }
+    };
+    if (bu0_on) bar(qU0, Ua[0]);
+    if (bu1_on) bar(qU1, Ua[1]);
+    if (by_on) bar(qY, Xa[1]);
+    if (bv_on) bar(qV, Xa[3]);
+    rRa = 0;
+    if (rr_on) { bar(qR, sRa); rRa = (Ua[0] - up0) - sRa; th += fabs(rRa); }
+#pragma unroll
+    for (int j = 0; j < NOBS; ++j) { rOa[j] = 0; if (ro_on[j]) { bar(qO, sOa[j]); rOa[j] = hval(j, Xa[0], Xa[1]) - sOa[j]; th += fabs(rOa[j]); } }
+    if (hasu) {   // objective terms of stage k (kin.py:195-205)
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { const double e = Xa[i] - xs[i]; fl += c.Q[i] * e * e; }
+      fl += c.R[0] * Ua[0] * Ua[0] + c.R[1] * Ua[1] * Ua[1];
       if (k > 0 || c.du0_cost) {
-        double d0 = Ua[0] - (k ? up0 : c.u_last[0]), d1 = Ua[1] - (k ? up1 : c.u_last[1]);
-        f += c.DR[0] * d0 * d0 + c.DR[1] * d1 * d1;
+        const double d0 = Ua[0] - (k ? up0 : c.u_last[0]), d1 = Ua[1] - (k ? up1 : c.u_last[1]);
+        fl += c.DR[0] * d0 * d0 + c.DR[1] * d1 * d1;
       }
     }
-    return wv::sum(f);
+    return ok;
   };
 
-  // evaluation at the iterate: model, defects, row residuals, theta, f
-  auto eval_point = [&]() {
-    model();
-    double th = 0;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      double xn = wv::shfl(X[i], k + 1);
-      dfc[i] = hasu ? F[i] - xn : 0.0;
-      th += fabs(dfc[i]);
-    }
-    Up0 = wv::shfl(U[0], k - 1); Up1 = wv::shfl(U[1], k - 1);
-    if (rr_on) { rR = (U[0] - Up0) - sR; th += fabs(rR); }
-#pragma unroll
-    for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
-      rO[j] = hval(j, X[0], X[1]) - sO[j]; th += fabs(rO[j]);
-      gO0[j] = 2 * (X[0] - ox[j]) * ix2[j]; gO1[j] = 2 * (X[1] - oy[j]) * iy2[j];
-    }
-    theta = wv::sum(th);
-    fval = objective(X, U, Up0, Up1);
-  };
-
-  // barrier function of the current point
-  auto barrier_phi = [&](double mu_) {
-    double s = 0;
-    auto bar = [&](const Bnd& q, double v) {
-      if (q.hasL) s -= log(v - q.L);
-      if (q.hasU) s -= log(q.U - v);
-    };
-    if (bu0_on) bar(qU0, U[0]);
-    if (bu1_on) bar(qU1, U[1]);
-    if (by_on) bar(qY, X[1]);
-    if (bv_on) bar(qV, X[3]);
-    if (rr_on) bar(qR, sR);
-#pragma unroll
-    for (int j = 0; j < NOBS; ++j) if (ro_on[j]) bar(qO, sO[j]);
-    return os * fval + mu_ * wv::sum(s);
-  };
-
-  // number of multipliers (constant): equality multipliers NX*N, bound multipliers
+  // number of multipliers (constants of the problem)
   double n_lam, n_v;
   {
     double cnt = 0;
@@ -333,74 +351,9 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     if (rr_on) cnt += two(qR);
 #pragma unroll
     for (int j = 0; j < NOBS; ++j) if (ro_on[j]) cnt += 1.0;
-    n_v = wv::sum(cnt);
+    n_v = wv::uni(wv::sum(cnt));
     n_lam = (double)(NX * N);
   }
-
-  // scaled KKT error pieces at barrier parameter mu_
-  double e_dual, e_prim, e_comp, e_sd, e_sc;
-  auto kkt_error = [&](double mu_) {
-    double rX[NX] = {0, 0, 0, 0}, rU[NU] = {0, 0};
-    double ln[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) ln[i] = wv::shfl(lam[i], k + 1);          // lam_{k+1}
-    const double Un0 = wv::shfl(U[0], k + 1), Un1 = wv::shfl(U[1], k + 1);
-    const double yR = rr_on ? dual_y(qR, vRL, vRU) : 0.0;
-    const double yRn = wv::shfl(yR, k + 1);
-    double sum_lam = 0, sum_v = 0, comp = 0, prim = 0;
-    if (xnode) {
-      if (k < N) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) rX[i] += os * 2 * c.Q[i] * (X[i] - xs[i]);
-      }
-#pragma unroll
-      for (int i = 0; i < NX; ++i) { rX[i] -= lam[i]; sum_lam += fabs(lam[i]); }
-      if (k < N) {   // A^T lam_{k+1}
-        rX[0] += ln[0]; rX[1] += ln[1];
-        rX[2] += a02 * ln[0] + a12 * ln[1] + ln[2];
-        rX[3] += a03 * ln[0] + a13 * ln[1] + a23 * ln[2] + ln[3];
-      }
-    }
-    if (hasu) {
-      rU[0] += os * 2 * c.R[0] * U[0]; rU[1] += os * 2 * c.R[1] * U[1];
-      if (k > 0 || c.du0_cost) {
-        rU[0] += os * 2 * c.DR[0] * (U[0] - (k ? Up0 : c.u_last[0]));
-        rU[1] += os * 2 * c.DR[1] * (U[1] - (k ? Up1 : c.u_last[1]));
-      }
-      if (k + 1 < N) { rU[0] -= os * 2 * c.DR[0] * (Un0 - U[0]); rU[1] -= os * 2 * c.DR[1] * (Un1 - U[1]); }
-      rU[0] += b20 * ln[2]; rU[1] += T * ln[3];
-      if (k + 1 < N) rU[0] += yRn;                                          // d(row k+1)/dU_k = -1
-    }
-    auto item = [&](const Bnd& q, double s, double vL, double vU) {
-      if (q.hasL) { comp = fmax(comp, fabs((s - q.L) * vL - mu_)); sum_v += vL; }
-      if (q.hasU) { comp = fmax(comp, fabs((q.U - s) * vU - mu_)); sum_v += vU; }
-    };
-    if (bu0_on) { rU[0] -= dual_y(qU0, zU0L, zU0U); item(qU0, U[0], zU0L, zU0U); }
-    if (bu1_on) { rU[1] -= dual_y(qU1, zU1L, zU1U); item(qU1, U[1], zU1L, zU1U); }
-    if (by_on) { rX[1] -= dual_y(qY, zYL, zYU); item(qY, X[1], zYL, zYU); }
-    if (bv_on) { rX[3] -= dual_y(qV, zVL, zVU); item(qV, X[3], zVL, zVU); }
-    if (rr_on) { rU[0] -= yR; item(qR, sR, vRL, vRU); prim = fmax(prim, fabs(rR)); }
-#pragma unroll
-    for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
-      rX[0] -= vO[j] * gO0[j]; rX[1] -= vO[j] * gO1[j];
-      item(qO, sO[j], vO[j], 0.0); prim = fmax(prim, fabs(rO[j]));
-    }
-    double dual = 0;
-    if (xnode) {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) dual = fmax(dual, fabs(rX[i]));
-    }
-    if (hasu) {
-      dual = fmax(dual, fmax(fabs(rU[0]), fabs(rU[1])));
-#pragma unroll
-      for (int i = 0; i < NX; ++i) prim = fmax(prim, fabs(dfc[i]));
-    }
-    e_dual = wv::max(dual); e_prim = wv::max(prim); e_comp = wv::max(comp);
-    sum_lam = wv::sum(sum_lam); sum_v = wv::sum(sum_v);
-    e_sd = fmax(S_MAX, (sum_lam + sum_v) / fmax(1.0, n_lam + n_v)) / S_MAX;
-    e_sc = fmax(S_MAX, sum_v / fmax(1.0, n_v)) / S_MAX;
-    return fmax(e_dual / e_sd, fmax(e_prim, e_comp / e_sc));
-  };
 
   // ----- per-lane constants of the Riccati sweep: lane = entry (i, j) of the 8x8 stage block -------------------
   const int ei = lane >> 3, ej = lane & 7;
@@ -442,103 +395,176 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
 #pragma unroll
   for (int r = 0; r < NA; ++r) { sABj[r] = slotAB(r, ej) * ld; sABi[r] = slotAB(r, ei) * ld; }
   const int sHij = slotH(ei, ej) * ld, sGi = (E_G0 + ei) * ld;
+  const int eiA = ei < NA ? ei : 0;           // clamped row for lanes of the control rows (their W is unused)
 
   // constant rows of the entry table
   if (isnode) { ent[E_ZERO * ld + k] = 0.0; ent[E_ONE * ld + k] = 1.0; ent[E_T * ld + k] = T; }
 
   double* Pst = lds + L.Pst; double* pst = lds + L.pst; double* Kst = lds + L.Kst; double* kffs = lds + L.kff;
-  double* Wl = lds + L.W; double* ql = lds + L.q; double* Ml = lds + L.M; double* ml = lds + L.m;
-  double* dXs = lds + L.dX; double* dUs = lds + L.dU; double* filt = lds + L.filt;
+  double* Wl = lds + L.W; double* ql = lds + L.q; double* filt = lds + L.filt;
   int nfilt = 0;
   double theta_max = 0, theta_min = 0;
   double dw_last = 0.0;
   const double mu_floor = c.tol / (K_EPS + 1.0);
-  double err0 = 0;
-
-  // step (per node lane)
-  double dX[NX] = {0, 0, 0, 0}, dU[NU] = {0, 0}, lamF[NX] = {0, 0, 0, 0};
-  double dzU0L = 0, dzU0U = 0, dzU1L = 0, dzU1U = 0, dzYL = 0, dzYU = 0, dzVL = 0, dzVU = 0;
-  double dsR = 0, dvRL = 0, dvRU = 0;
-  double dsO[NOBS > 0 ? NOBS : 1], dvO[NOBS > 0 ? NOBS : 1];
+  double err0 = 0, e_dual = 0, e_prim = 0;
 
   if (status != MPCB_ST_INFEASIBLE_X0) {
-    eval_point();
-    theta_max = 1e4 * fmax(1.0, theta); theta_min = 1e-4 * fmax(1.0, theta);
+    // evaluation at the start point
+    {
+      trig(X[2], U[0], sp, cp, td, sec2);
+      double th, fl, prod;
+      eval_lane(X, U, sR, sO, sp, cp, td, dfc, rR, rO, Up0, Up1, th, fl, prod);
+      double sv[3] = {th, fl, log(prod)};
+      wv::reduce<3, 0>(sv, nullptr);
+      theta = wv::uni(sv[0]); fval = wv::uni(sv[1]); logsum = wv::uni(sv[2]);
+      recips();
+#pragma unroll
+      for (int j = 0; j < NOBS; ++j) if (ro_on[j]) { gO0[j] = 2 * (X[0] - ox[j]) * ix2[j]; gO1[j] = 2 * (X[1] - oy[j]) * iy2[j]; }
+    }
+    theta_max = wv::uni(1e4 * fmax(1.0, theta)); theta_min = wv::uni(1e-4 * fmax(1.0, theta));
 
+#pragma clang loop unroll(disable)
     for (iters = 0;; ++iters) {
-      err0 = kkt_error(0.0);
-      if (a.trace && b == a.trace_instance && lane == 0) {
-        double* t = a.trace + (size_t)iters * 8;
-        t[0] = mu; t[1] = err0; t[2] = theta; t[3] = fval;
-      }
-      if (err0 <= c.tol) { status = MPCB_ST_SOLVED; break; }
-      if (iters >= c.max_iter) { status = MPCB_ST_MAXITER; break; }
-
-      // barrier parameter update (monotone, Fiacco-McCormick)
-      for (;;) {
-        double em = kkt_error(mu);
-        if (em <= K_EPS * mu && mu > mu_floor) {
-          mu = fmax(mu_floor, fmin(K_MU * mu, pow(mu, TH_MU)));
-          tau = fmax(TAU_MIN, 1.0 - mu);
-          nfilt = 0;
-        } else break;
+      // ----- KKT residuals of the scaled problem at the iterate (one pass, fused reductions) ---------------------
+      const double a02 = -T * X[3] * sp, a03 = T * cp, a12 = T * X[3] * cp, a13 = T * sp, a23 = T * td * il, b20 = T * X[3] * sec2 * il;
+      double ln[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) ln[i] = wv::shfl(lam[i], k + 1);          // lam_{k+1}
+      {
+        double rX[NX] = {0, 0, 0, 0}, rU[NU] = {0, 0};
+        const double Un0 = wv::shfl(U[0], k + 1), Un1 = wv::shfl(U[1], k + 1);
+        const double yR = rr_on ? item_y(qR, iR) : 0.0;
+        const double yRn = wv::shfl(yR, k + 1);
+        double sum_lam = 0, sum_v = 0, svmax = 0, svmin = 1e300, prim = 0;
+        if (xnode) {
+          if (k < N) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) rX[i] += os * 2 * c.Q[i] * (X[i] - xs[i]);
+          }
+#pragma unroll
+          for (int i = 0; i < NX; ++i) { rX[i] -= lam[i]; sum_lam += fabs(lam[i]); }
+          if (k < N) {   // A^T lam_{k+1}
+            rX[0] += ln[0]; rX[1] += ln[1];
+            rX[2] += a02 * ln[0] + a12 * ln[1] + ln[2];
+            rX[3] += a03 * ln[0] + a13 * ln[1] + a23 * ln[2] + ln[3];
+          }
+        }
+        if (hasu) {
+          rU[0] += os * 2 * c.R[0] * U[0]; rU[1] += os * 2 * c.R[1] * U[1];
+          if (k > 0 || c.du0_cost) {
+            rU[0] += os * 2 * c.DR[0] * (U[0] - (k ? Up0 : c.u_last[0]));
+            rU[1] += os * 2 * c.DR[1] * (U[1] - (k ? Up1 : c.u_last[1]));
+          }
+          if (k + 1 < N) { rU[0] -= os * 2 * c.DR[0] * (Un0 - U[0]); rU[1] -= os * 2 * c.DR[1] * (Un1 - U[1]); }
+          rU[0] += b20 * ln[2]; rU[1] += T * ln[3];
+          if (k + 1 < N) rU[0] += yRn;                                          // d(row k+1)/dU_k = -1
+        }
+        auto item = [&](const Bnd& q, double s, const Item& it) {
+          if (q.hasL) { const double p = (s - q.L) * it.vL; svmax = fmax(svmax, p); svmin = fmin(svmin, p); sum_v += it.vL; }
+          if (q.hasU) { const double p = (q.U - s) * it.vU; svmax = fmax(svmax, p); svmin = fmin(svmin, p); sum_v += it.vU; }
+        };
+        if (bu0_on) { rU[0] -= item_y(qU0, iU0); item(qU0, U[0], iU0); }
+        if (bu1_on) { rU[1] -= item_y(qU1, iU1); item(qU1, U[1], iU1); }
+        if (by_on) { rX[1] -= item_y(qY, iY); item(qY, X[1], iY); }
+        if (bv_on) { rX[3] -= item_y(qV, iV); item(qV, X[3], iV); }
+        if (rr_on) { rU[0] -= yR; item(qR, sR, iR); prim = fmax(prim, fabs(rR)); }
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
+          rX[0] -= vO[j] * gO0[j]; rX[1] -= vO[j] * gO1[j];
+          const double p = (sO[j] - qO.L) * vO[j]; svmax = fmax(svmax, p); svmin = fmin(svmin, p); sum_v += vO[j];
+          prim = fmax(prim, fabs(rO[j]));
+        }
+        double dual = 0;
+        if (xnode) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) dual = fmax(dual, fabs(rX[i]));
+        }
+        if (hasu) {
+          dual = fmax(dual, fmax(fabs(rU[0]), fabs(rU[1])));
+#pragma unroll
+          for (int i = 0; i < NX; ++i) prim = fmax(prim, fabs(dfc[i]));
+        }
+        double ss[2] = {sum_lam, sum_v}, mm[4] = {dual, prim, svmax, -svmin};
+        wv::reduce<2, 4>(ss, mm);
+        e_dual = wv::uni(mm[0]); e_prim = wv::uni(mm[1]);
+        const double sv_hi = wv::uni(mm[2]), sv_lo = -wv::uni(mm[3]);
+        const double e_sd = fmax(S_MAX, (wv::uni(ss[0]) + wv::uni(ss[1])) / fmax(1.0, n_lam + n_v)) / S_MAX;
+        const double e_sc = fmax(S_MAX, wv::uni(ss[1]) / fmax(1.0, n_v)) / S_MAX;
+        const double base = fmax(e_dual / e_sd, e_prim);
+        err0 = fmax(base, (n_v > 0 ? sv_hi : 0.0) / e_sc);                       // complementarity error at mu = 0
+        if (a.trace && b == a.trace_instance && lane == 0) {
+          double* t = a.trace + (size_t)iters * 8;
+          t[0] = mu; t[1] = err0; t[2] = theta; t[3] = fval;
+        }
+        if (err0 <= c.tol) { status = MPCB_ST_SOLVED; break; }
+        if (iters >= c.max_iter) { status = MPCB_ST_MAXITER; break; }
+        // barrier parameter update (monotone, Fiacco-McCormick): max_i |s_i v_i - mu| from the two extremes
+        for (;;) {
+          const double comp = (n_v > 0) ? fmax(fabs(sv_hi - mu), fabs(sv_lo - mu)) : 0.0;
+          const double em = fmax(base, comp / e_sc);
+          if (em <= K_EPS * mu && mu > mu_floor) {
+            mu = wv::uni(fmax(mu_floor, fmin(K_MU * mu, mu * sqrt(mu))));
+            tau = wv::uni(fmax(TAU_MIN, 1.0 - mu));
+            nfilt = 0;
+          } else break;
+        }
       }
 
       // ----- condensed stage QP: lane k writes the compact entries of stage k ------------------------------------
-      double ln[NX];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) ln[i] = wv::shfl(lam[i], k + 1);
       double hxx = 0, hxy = 0, hyy = 0, hpp = 0, hpv = 0, hvv = 0, hvd = 0, hdd = 0, haa = 0, h44 = 0, h55 = 0, h46 = 0, h57 = 0;
-      double g[NW] = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (xcost) {
-        hxx += os * 2 * c.Q[0]; hyy += os * 2 * c.Q[1]; hpp += os * 2 * c.Q[2]; hvv += os * 2 * c.Q[3];
+      {
+        double g[NW] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (xcost) {
+          hxx += os * 2 * c.Q[0]; hyy += os * 2 * c.Q[1]; hpp += os * 2 * c.Q[2]; hvv += os * 2 * c.Q[3];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) g[i] += os * 2 * c.Q[i] * (X[i] - xs[i]);
-      }
-      if (hasu) {
-        hdd += os * 2 * c.R[0]; haa += os * 2 * c.R[1];
-        g[6] += os * 2 * c.R[0] * U[0]; g[7] += os * 2 * c.R[1] * U[1];
-        if (k > 0 || c.du0_cost) {
-          const double w0 = os * 2 * c.DR[0], w1 = os * 2 * c.DR[1];
-          const double d0 = U[0] - (k ? Up0 : c.u_last[0]), d1 = U[1] - (k ? Up1 : c.u_last[1]);
-          hdd += w0; h44 += w0; h46 -= w0; haa += w1; h55 += w1; h57 -= w1;
-          g[6] += w0 * d0; g[4] -= w0 * d0; g[7] += w1 * d1; g[5] -= w1 * d1;
+          for (int i = 0; i < NX; ++i) g[i] += os * 2 * c.Q[i] * (X[i] - xs[i]);
         }
-        // sum_a lam_{k+1,a} T d2f_a
-        const double v = X[3];
-        hpp += T * (-ln[0] * v * cp - ln[1] * v * sp);
-        hpv += T * (-ln[0] * sp + ln[1] * cp);
-        hvd += T * ln[2] * sec2 * il;
-        hdd += T * ln[2] * v * 2.0 * td * sec2 * il;
-      }
-      double sig, gb;
-      if (bu0_on) { sig_gb(qU0, U[0], zU0L, zU0U, 0.0, mu, sig, gb); hdd += sig; g[6] -= gb; }
-      if (bu1_on) { sig_gb(qU1, U[1], zU1L, zU1U, 0.0, mu, sig, gb); haa += sig; g[7] -= gb; }
-      if (by_on) { sig_gb(qY, X[1], zYL, zYU, 0.0, mu, sig, gb); hyy += sig; g[1] -= gb; }
-      if (bv_on) { sig_gb(qV, X[3], zVL, zVU, 0.0, mu, sig, gb); hvv += sig; g[3] -= gb; }
-      if (rr_on) { sig_gb(qR, sR, vRL, vRU, rR, mu, sig, gb); hdd += sig; h44 += sig; h46 -= sig; g[6] -= gb; g[4] += gb; }
+        if (hasu) {
+          hdd += os * 2 * c.R[0]; haa += os * 2 * c.R[1];
+          g[6] += os * 2 * c.R[0] * U[0]; g[7] += os * 2 * c.R[1] * U[1];
+          if (k > 0 || c.du0_cost) {
+            const double w0 = os * 2 * c.DR[0], w1 = os * 2 * c.DR[1];
+            const double d0 = U[0] - (k ? Up0 : c.u_last[0]), d1 = U[1] - (k ? Up1 : c.u_last[1]);
+            hdd += w0; h44 += w0; h46 -= w0; haa += w1; h55 += w1; h57 -= w1;
+            g[6] += w0 * d0; g[4] -= w0 * d0; g[7] += w1 * d1; g[5] -= w1 * d1;
+          }
+          // sum_a lam_{k+1,a} T d2f_a
+          const double v = X[3];
+          hpp += T * (-ln[0] * v * cp - ln[1] * v * sp);
+          hpv += T * (-ln[0] * sp + ln[1] * cp);
+          hvd += T * ln[2] * sec2 * il;
+          hdd += T * ln[2] * v * 2.0 * td * sec2 * il;
+        }
+        double sig, gb;
+        if (bu0_on) { item_sig_gb(iU0, 0.0, mu, sig, gb); hdd += sig; g[6] -= gb; }
+        if (bu1_on) { item_sig_gb(iU1, 0.0, mu, sig, gb); haa += sig; g[7] -= gb; }
+        if (by_on) { item_sig_gb(iY, 0.0, mu, sig, gb); hyy += sig; g[1] -= gb; }
+        if (bv_on) { item_sig_gb(iV, 0.0, mu, sig, gb); hvv += sig; g[3] -= gb; }
+        if (rr_on) { item_sig_gb(iR, rR, mu, sig, gb); hdd += sig; h44 += sig; h46 -= sig; g[6] -= gb; g[4] += gb; }
 #pragma unroll
-      for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
-        sig_gb(qO, sO[j], vO[j], 0.0, rO[j], mu, sig, gb);
-        hxx += sig * gO0[j] * gO0[j] - vO[j] * 2 * ix2[j];
-        hxy += sig * gO0[j] * gO1[j];
-        hyy += sig * gO1[j] * gO1[j] - vO[j] * 2 * iy2[j];
-        g[0] -= gb * gO0[j]; g[1] -= gb * gO1[j];
-      }
-      if (isnode) {
-        ent[E_A02 * ld + k] = hasu ? a02 : 0.0; ent[E_A03 * ld + k] = hasu ? a03 : 0.0;
-        ent[E_A12 * ld + k] = hasu ? a12 : 0.0; ent[E_A13 * ld + k] = hasu ? a13 : 0.0;
-        ent[E_A23 * ld + k] = hasu ? a23 : 0.0; ent[E_B20 * ld + k] = hasu ? b20 : 0.0;
+        for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
+          sig = vO[j] * iO[j]; gb = mu * iO[j] - sig * rO[j];
+          hxx += sig * gO0[j] * gO0[j] - vO[j] * 2 * ix2[j];
+          hxy += sig * gO0[j] * gO1[j];
+          hyy += sig * gO1[j] * gO1[j] - vO[j] * 2 * iy2[j];
+          g[0] -= gb * gO0[j]; g[1] -= gb * gO1[j];
+        }
+        if (isnode) {
+          ent[E_A02 * ld + k] = hasu ? a02 : 0.0; ent[E_A03 * ld + k] = hasu ? a03 : 0.0;
+          ent[E_A12 * ld + k] = hasu ? a12 : 0.0; ent[E_A13 * ld + k] = hasu ? a13 : 0.0;
+          ent[E_A23 * ld + k] = hasu ? a23 : 0.0; ent[E_B20 * ld + k] = hasu ? b20 : 0.0;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) ent[(E_D0 + i) * ld + k] = dfc[i];
+          for (int i = 0; i < NX; ++i) ent[(E_D0 + i) * ld + k] = dfc[i];
 #pragma unroll
-        for (int i = 0; i < NW; ++i) ent[(E_G0 + i) * ld + k] = g[i];
-        ent[E_HXY * ld + k] = hxy; ent[E_HPV * ld + k] = hpv; ent[E_HVD * ld + k] = hvd;
-        ent[E_H44 * ld + k] = h44; ent[E_H55 * ld + k] = h55; ent[E_H46 * ld + k] = h46; ent[E_H57 * ld + k] = h57;
+          for (int i = 0; i < NW; ++i) ent[(E_G0 + i) * ld + k] = g[i];
+          ent[E_HXY * ld + k] = hxy; ent[E_HPV * ld + k] = hpv; ent[E_HVD * ld + k] = hvd;
+          ent[E_H44 * ld + k] = h44; ent[E_H55 * ld + k] = h55; ent[E_H46 * ld + k] = h46; ent[E_H57 * ld + k] = h57;
+        }
       }
 
       // ----- factorisation with inertia correction: backward Riccati sweep, lanes = entries ----------------------
       double dw = 0.0; bool first_try = true, fact_ok = false;
+#pragma clang loop unroll(disable)
       for (int tries = 0; tries < 60; ++tries) {
         if (isnode) {
           ent[E_HXX * ld + k] = hxx + (xnode ? dw : 0.0); ent[E_HYY * ld + k] = hyy + (xnode ? dw : 0.0);
@@ -551,52 +577,41 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         if (ei < NA && ej == 0) pst[N * NA + ei] = ent[sGi + N];
         wv::sync();
         bool pd = true;
+#pragma clang loop unroll(disable)
         for (int s = N - 1; s >= 0; --s) {
-          double abj[NA], abi[NA];
+          // W = P+ [A B],  q = p+ + P+ d          (lane (i,j): row i of P+, column j of [A B])
+          const double* Pn = Pst + (s + 1) * NA * NA + eiA * NA;
+          double* Wb = Wl + (s & 1) * NW * NA; double* qb = ql + (s & 1) * NW;
+          double w = 0, qv = pst[(s + 1) * NA + eiA];
 #pragma unroll
-          for (int r = 0; r < NA; ++r) { abj[r] = ent[sABj[r] + s]; abi[r] = ent[sABi[r] + s]; }
-          const double hij = ent[sHij + s], gi = ent[sGi + s];
-          const double* Pn = Pst + (s + 1) * NA * NA;
-          const double* pn = pst + (s + 1) * NA;
-          if (ei < NA) {
-            double w = 0, q = pn[ei];
+          for (int r = 0; r < NA; ++r) w += Pn[r] * ent[sABj[r] + s];
 #pragma unroll
-            for (int r = 0; r < NA; ++r) w += Pn[ei * NA + r] * abj[r];
-#pragma unroll
-            for (int r = 0; r < NX; ++r) q += Pn[ei * NA + r] * ent[(E_D0 + r) * ld + s];
-            Wl[ej * NA + ei] = w;
-            if (ej == 0) ql[ei] = q;
-          }
+          for (int r = 0; r < NX; ++r) qv += Pn[r] * ent[(E_D0 + r) * ld + s];
+          if (ei < NA) { Wb[ej * NA + ei] = w; if (ej == 0) qb[ei] = qv; }
           wv::sync();
-          {
-            double Mij = hij, mi = gi;
+          // M = H + [A B]^T W,  m = g + [A B]^T q
+          double Mij = ent[sHij + s], mi = ent[sGi + s];
 #pragma unroll
-            for (int r = 0; r < NA; ++r) { Mij += abi[r] * Wl[ej * NA + r]; mi += abi[r] * ql[r]; }
-            Ml[ei * NW + ej] = Mij;
-            if (ej == 0) ml[ei] = mi;
-          }
-          wv::sync();
-          const double m11 = Ml[NA * NW + NA], m12 = 0.5 * (Ml[NA * NW + NA + 1] + Ml[(NA + 1) * NW + NA]), m22 = Ml[(NA + 1) * NW + NA + 1];
+          for (int r = 0; r < NA; ++r) { const double ab = ent[sABi[r] + s]; Mij += ab * Wb[ej * NA + r]; mi += ab * qb[r]; }
+          // control block Muu (lanes (6,6),(6,7),(7,6),(7,7)) and m_u (lanes (6,*),(7,*)) to every lane
+          const double m11 = wv::bcast(Mij, NA * 8 + NA), m12 = 0.5 * (wv::bcast(Mij, NA * 8 + NA + 1) + wv::bcast(Mij, (NA + 1) * 8 + NA));
+          const double m22 = wv::bcast(Mij, (NA + 1) * 8 + NA + 1);
+          const double mu6 = wv::bcast(mi, NA * 8), mu7 = wv::bcast(mi, (NA + 1) * 8);
           const double det = m11 * m22 - m12 * m12;
           if (!(m11 > 0) || !(det > 1e-14 * m11 * m22) || !isfinite(det)) { pd = false; break; }
-          const double i11 = m22 / det, i12 = -m12 / det, i22 = m11 / det;
-          const double mu6 = ml[NA], mu7 = ml[NA + 1];
+          const double idet = 1.0 / det;
+          const double i11 = m22 * idet, i12 = -m12 * idet, i22 = m11 * idet;
           const double kf0 = -(i11 * mu6 + i12 * mu7), kf1 = -(i12 * mu6 + i22 * mu7);
+          // rows 6,7 of M at column j, and (by symmetry of the exchange pattern) at column i
+          const double M6j = wv::shfl(Mij, NA * 8 + ej), M7j = wv::shfl(Mij, (NA + 1) * 8 + ej);
+          const double M6i = wv::shfl(Mij, NA * 8 + ei), M7i = wv::shfl(Mij, (NA + 1) * 8 + ei);
+          const double K0j = -(i11 * M6j + i12 * M7j), K1j = -(i12 * M6j + i22 * M7j);
           if (ei < NA && ej < NA) {
-            const double M6j = Ml[NA * NW + ej], M7j = Ml[(NA + 1) * NW + ej];
-            const double Mi6 = Ml[ei * NW + NA], Mi7 = Ml[ei * NW + NA + 1];
-            const double K0j = -(i11 * M6j + i12 * M7j), K1j = -(i12 * M6j + i22 * M7j);
-            Pst[s * NA * NA + ei * NA + ej] = Ml[ei * NW + ej] + Mi6 * K0j + Mi7 * K1j;
+            Pst[s * NA * NA + ei * NA + ej] = Mij + M6i * K0j + M7i * K1j;
             if (ei == 0) { Kst[s * 2 * NA + ej] = K0j; Kst[s * 2 * NA + NA + ej] = K1j; }
-            if (ej == 0) pst[s * NA + ei] = ml[ei] + Mi6 * kf0 + Mi7 * kf1;
+            if (ej == 0) pst[s * NA + ei] = mi + M6i * kf0 + M7i * kf1;
           }
           if (lane == 0) { kffs[s * 2] = kf0; kffs[s * 2 + 1] = kf1; }
-          wv::sync();
-          // symmetrise P_s (keeps the recursion symmetric to rounding)
-          if (ei < NA && ej < NA && ei < ej) {
-            double sym = 0.5 * (Pst[s * NA * NA + ei * NA + ej] + Pst[s * NA * NA + ej * NA + ei]);
-            Pst[s * NA * NA + ei * NA + ej] = sym; Pst[s * NA * NA + ej * NA + ei] = sym;
-          }
           wv::sync();
         }
         if (pd) { fact_ok = true; if (dw > 0) dw_last = dw; break; }
@@ -606,34 +621,27 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       }
       if (!fact_ok) { status = MPCB_ST_NUMERIC; break; }
 
-      // ----- forward roll-out of the step (every lane carries the same 6-vector) ---------------------------------
+      // ----- forward roll-out of the step: every lane carries the same 6-vector, lane k latches its node ----------
+      double dX[NX] = {0, 0, 0, 0}, dU[NU] = {0, 0};
       {
-        double dx[NA] = {0, 0, 0, 0, 0, 0};
-        if (lane == 0) { dXs[0] = 0; dXs[1] = 0; dXs[2] = 0; dXs[3] = 0; }
+        double dx0 = 0, dx1 = 0, dx2 = 0, dx3 = 0, dx4 = 0, dx5 = 0;
+#pragma unroll 2
         for (int s = 0; s < N; ++s) {
           const double* Ks = Kst + s * 2 * NA;
-          double du0 = kffs[s * 2], du1 = kffs[s * 2 + 1];
-#pragma unroll
-          for (int r = 0; r < NA; ++r) { du0 += Ks[r] * dx[r]; du1 += Ks[NA + r] * dx[r]; }
-          const double A02 = ent[E_A02 * ld + s], A03 = ent[E_A03 * ld + s], A12 = ent[E_A12 * ld + s], A13 = ent[E_A13 * ld + s];
-          const double A23 = ent[E_A23 * ld + s], B20 = ent[E_B20 * ld + s];
-          const double n0 = dx[0] + A02 * dx[2] + A03 * dx[3] + ent[E_D0 * ld + s];
-          const double n1 = dx[1] + A12 * dx[2] + A13 * dx[3] + ent[E_D1 * ld + s];
-          const double n2 = dx[2] + A23 * dx[3] + B20 * du0 + ent[E_D2 * ld + s];
-          const double n3 = dx[3] + T * du1 + ent[E_D3 * ld + s];
-          dx[0] = n0; dx[1] = n1; dx[2] = n2; dx[3] = n3; dx[4] = du0; dx[5] = du1;
-          if (lane == 0) {
-            dUs[s * 2] = du0; dUs[s * 2 + 1] = du1;
-            dXs[(s + 1) * NX + 0] = n0; dXs[(s + 1) * NX + 1] = n1; dXs[(s + 1) * NX + 2] = n2; dXs[(s + 1) * NX + 3] = n3;
-          }
+          const double du0 = kffs[s * 2] + (Ks[0] * dx0 + Ks[1] * dx1) + (Ks[2] * dx2 + Ks[3] * dx3) + (Ks[4] * dx4 + Ks[5] * dx5);
+          const double du1 = kffs[s * 2 + 1] + (Ks[6] * dx0 + Ks[7] * dx1) + (Ks[8] * dx2 + Ks[9] * dx3) + (Ks[10] * dx4 + Ks[11] * dx5);
+          const double n0 = dx0 + ent[E_A02 * ld + s] * dx2 + ent[E_A03 * ld + s] * dx3 + ent[E_D0 * ld + s];
+          const double n1 = dx1 + ent[E_A12 * ld + s] * dx2 + ent[E_A13 * ld + s] * dx3 + ent[E_D1 * ld + s];
+          const double n2 = dx2 + ent[E_A23 * ld + s] * dx3 + ent[E_B20 * ld + s] * du0 + ent[E_D2 * ld + s];
+          const double n3 = dx3 + T * du1 + ent[E_D3 * ld + s];
+          if (k == s) { dU[0] = du0; dU[1] = du1; }
+          if (k == s + 1) { dX[0] = n0; dX[1] = n1; dX[2] = n2; dX[3] = n3; }
+          dx0 = n0; dx1 = n1; dx2 = n2; dx3 = n3; dx4 = du0; dx5 = du1;
         }
-        wv::sync();
-#pragma unroll
-        for (int i = 0; i < NX; ++i) dX[i] = isnode ? dXs[k * NX + i] : 0.0;
-        dU[0] = hasu ? dUs[k * 2] : 0.0; dU[1] = hasu ? dUs[k * 2 + 1] : 0.0;
       }
       const double dUp0 = wv::shfl(dU[0], k - 1), dUp1 = wv::shfl(dU[1], k - 1);   // dU_{k-1}
       // costate of the full step: lamF_k = P_k [dX_k; dU_{k-1}] + p_k  (node-parallel)
+      double lamF[NX] = {0, 0, 0, 0};
       if (xnode) {
         const double* Pk = Pst + k * NA * NA;
         const double dxa[NA] = {dX[0], dX[1], dX[2], dX[3], dUp0, dUp1};
@@ -645,48 +653,31 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           lamF[i] = s;
         }
       }
-      // slack and dual steps
-      auto dstep = [&](const Bnd& q, double s, double ds, double vL, double vU, double& dvL, double& dvU) {
-        dvL = 0; dvU = 0;
-        if (q.hasL) { double d = s - q.L; dvL = mu / d - vL - vL / d * ds; }
-        if (q.hasU) { double d = q.U - s; dvU = mu / d - vU + vU / d * ds; }
-      };
-      if (bu0_on) dstep(qU0, U[0], dU[0], zU0L, zU0U, dzU0L, dzU0U);
-      if (bu1_on) dstep(qU1, U[1], dU[1], zU1L, zU1U, dzU1L, dzU1U);
-      if (by_on) dstep(qY, X[1], dX[1], zYL, zYU, dzYL, dzYU);
-      if (bv_on) dstep(qV, X[3], dX[3], zVL, zVU, dzVL, dzVU);
-      if (rr_on) { dsR = (dU[0] - dUp0) + rR; dstep(qR, sR, dsR, vRL, vRU, dvRL, dvRU); }
+      // slack steps of the general rows
+      const double dsR = rr_on ? (dU[0] - dUp0) + rR : 0.0;
+      double dsO[NOB];
 #pragma unroll
-      for (int j = 0; j < NOBS; ++j) {
-        dsO[j] = 0; dvO[j] = 0;
-        if (ro_on[j]) { double dummy; dsO[j] = gO0[j] * dX[0] + gO1[j] * dX[1] + rO[j]; dstep(qO, sO[j], dsO[j], vO[j], 0.0, dvO[j], dummy); }
-      }
+      for (int j = 0; j < NOBS; ++j) dsO[j] = ro_on[j] ? gO0[j] * dX[0] + gO1[j] * dX[1] + rO[j] : 0.0;
 
-      // ----- fraction to the boundary -----------------------------------------------------------------------------
-      double a_pr = 1.0, a_du = 1.0;
-      auto ftb = [&](const Bnd& q, double s, double ds, double vL, double vU, double dvL, double dvU) {
-        if (q.hasL) {
-          if (ds < 0) a_pr = fmin(a_pr, -tau * (s - q.L) / ds);
-          if (dvL < 0) a_du = fmin(a_du, -tau * vL / dvL);
-        }
-        if (q.hasU) {
-          if (ds > 0) a_pr = fmin(a_pr, tau * (q.U - s) / ds);
-          if (dvU < 0) a_du = fmin(a_du, -tau * vU / dvU);
-        }
-      };
-      if (bu0_on) ftb(qU0, U[0], dU[0], zU0L, zU0U, dzU0L, dzU0U);
-      if (bu1_on) ftb(qU1, U[1], dU[1], zU1L, zU1U, dzU1L, dzU1U);
-      if (by_on) ftb(qY, X[1], dX[1], zYL, zYU, dzYL, dzYU);
-      if (bv_on) ftb(qV, X[3], dX[3], zVL, zVU, dzVL, dzVU);
-      if (rr_on) ftb(qR, sR, dsR, vRL, vRU, dvRL, dvRU);
-#pragma unroll
-      for (int j = 0; j < NOBS; ++j) if (ro_on[j]) ftb(qO, sO[j], dsO[j], vO[j], 0.0, dvO[j], 0.0);
-      a_pr = wv::min(a_pr); a_du = wv::min(a_du);
-
-      // ----- directional derivative of the barrier function -----------------------------------------------------
-      double dphi;
+      // ----- fraction to the boundary (as the largest step ratios) and d(barrier function) along the step --------
+      double a_pr, a_du, dphi;
       {
-        double d = 0;
+        double rpr = 0, rdu = 0, d = 0;
+        auto ftb = [&](const Bnd& q, const Item& it, double ds) {
+          double dvL, dvU; item_dv(q, it, ds, mu, dvL, dvU);
+          if (q.hasL) { rpr = fmax(rpr, -ds * it.iL); rdu = fmax(rdu, -dvL * wv::rcp(it.vL)); d -= mu * ds * it.iL; }
+          if (q.hasU) { rpr = fmax(rpr, ds * it.iU); rdu = fmax(rdu, -dvU * wv::rcp(it.vU)); d += mu * ds * it.iU; }
+        };
+        if (bu0_on) ftb(qU0, iU0, dU[0]);
+        if (bu1_on) ftb(qU1, iU1, dU[1]);
+        if (by_on) ftb(qY, iY, dX[1]);
+        if (bv_on) ftb(qV, iV, dX[3]);
+        if (rr_on) ftb(qR, iR, dsR);
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
+          const double dv = mu * iO[j] - vO[j] - vO[j] * iO[j] * dsO[j];
+          rpr = fmax(rpr, -dsO[j] * iO[j]); rdu = fmax(rdu, -dv * wv::rcp(vO[j])); d -= mu * dsO[j] * iO[j];
+        }
         if (xcost) {
 #pragma unroll
           for (int i = 0; i < NX; ++i) d += os * 2 * c.Q[i] * (X[i] - xs[i]) * dX[i];
@@ -698,69 +689,53 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
             d += os * 2 * c.DR[1] * (U[1] - (k ? Up1 : c.u_last[1])) * (dU[1] - (k ? dUp1 : 0.0));
           }
         }
-        auto bd = [&](const Bnd& q, double s, double ds) {
-          if (q.hasL) d -= mu * ds / (s - q.L);
-          if (q.hasU) d += mu * ds / (q.U - s);
-        };
-        if (bu0_on) bd(qU0, U[0], dU[0]);
-        if (bu1_on) bd(qU1, U[1], dU[1]);
-        if (by_on) bd(qY, X[1], dX[1]);
-        if (bv_on) bd(qV, X[3], dX[3]);
-        if (rr_on) bd(qR, sR, dsR);
-#pragma unroll
-        for (int j = 0; j < NOBS; ++j) if (ro_on[j]) bd(qO, sO[j], dsO[j]);
-        dphi = wv::sum(d);
+        double ss[1] = {d}, mm[2] = {rpr, rdu};
+        wv::reduce<1, 2>(ss, mm);
+        dphi = wv::uni(ss[0]);
+        const double r1 = wv::uni(mm[0]), r2 = wv::uni(mm[1]);
+        a_pr = wv::uni((r1 > tau) ? tau / r1 : 1.0);          // min(1, tau / max ratio)
+        a_du = wv::uni((r2 > tau) ? tau / r2 : 1.0);
       }
-      const double phi0 = barrier_phi(mu), th0 = theta;
+      const double phi0 = wv::uni(os * fval - mu * logsum), th0 = theta;
       double a_min;
       if (dphi < 0) {
         a_min = fmin(G_THETA, G_PHI * th0 / (-dphi));
         if (th0 <= theta_min) a_min = fmin(a_min, DELTA * pow(th0, S_THETA) / pow(-dphi, S_PHI));
       } else a_min = G_THETA;
-      a_min *= G_ALPHA;
+      a_min = wv::uni(a_min * G_ALPHA);
 
       // ----- filter line search: trial evaluations are lane-parallel ----------------------------------------------
       double alpha = a_pr; bool accepted = false, armijo_type = false;
+      double Xt[NX], Ut[NU], dft[NX], sRt, rRt, sOt[NOB], rOt[NOB], upt0, upt1, st_, ct_, tt_, et_, tht = 0, ft = 0, lst = 0;
+#pragma clang loop unroll(disable)
       for (;;) {
-        double Xt[NX], Ut[NU];
 #pragma unroll
         for (int i = 0; i < NX; ++i) Xt[i] = X[i] + alpha * dX[i];
         Ut[0] = U[0] + alpha * dU[0]; Ut[1] = U[1] + alpha * dU[1];
-        double th = 0, bs = 0; bool ok = true;
-        {
-          const double s_ = sin(Xt[2]), c_ = cos(Xt[2]), t_ = tan(Ut[0]), v = Xt[3];
-          const double Ft[NX] = {Xt[0] + T * (v * c_), Xt[1] + T * (v * s_), Xt[2] + T * (v * t_ * il), Xt[3] + T * Ut[1]};
+        sRt = sR + alpha * dsR;
 #pragma unroll
-          for (int i = 0; i < NX; ++i) { double xn = wv::shfl(Xt[i], k + 1); if (hasu) th += fabs(Ft[i] - xn); }
-        }
-        const double Utp0 = wv::shfl(Ut[0], k - 1), Utp1 = wv::shfl(Ut[1], k - 1);
-        auto bar = [&](const Bnd& q, double s) {
-          if (q.hasL) { double d = s - q.L; if (!(d > 0)) ok = false; else bs -= log(d); }
-          if (q.hasU) { double d = q.U - s; if (!(d > 0)) ok = false; else bs -= log(d); }
-        };
-        if (bu0_on) bar(qU0, Ut[0]);
-        if (bu1_on) bar(qU1, Ut[1]);
-        if (by_on) bar(qY, Xt[1]);
-        if (bv_on) bar(qV, Xt[3]);
-        if (rr_on) { double s = sR + alpha * dsR; bar(qR, s); th += fabs((Ut[0] - Utp0) - s); }
-#pragma unroll
-        for (int j = 0; j < NOBS; ++j) if (ro_on[j]) { double s = sO[j] + alpha * dsO[j]; bar(qO, s); th += fabs(hval(j, Xt[0], Xt[1]) - s); }
-        const double tht = wv::sum(th);
-        const double ft = objective(Xt, Ut, Utp0, Utp1);
-        const double phit = os * ft + mu * wv::sum(bs);
-        ok = wv::all(ok) && isfinite(tht) && isfinite(phit);
+        for (int j = 0; j < NOBS; ++j) sOt[j] = sO[j] + alpha * dsO[j];
+        trig(Xt[2], Ut[0], st_, ct_, tt_, et_);
+        double th, fl, prod;
+        const bool okl = eval_lane(Xt, Ut, sRt, sOt, st_, ct_, tt_, dft, rRt, rOt, upt0, upt1, th, fl, prod);
+        double sv[4] = {th, fl, okl ? log(prod) : 0.0, okl ? 0.0 : 1.0};
+        wv::reduce<4, 0>(sv, nullptr);
+        tht = wv::uni(sv[0]); ft = wv::uni(sv[1]); lst = wv::uni(sv[2]);
+        const double phit = os * ft - mu * lst;
+        const bool ok = (wv::uni(sv[3]) == 0.0) && isfinite(tht) && isfinite(phit);
         if (ok && tht <= theta_max) {
           bool fok = true;
           for (int e = lane; e < nfilt; e += 64) if (tht >= filt[2 * e] && phit >= filt[2 * e + 1]) fok = false;
           if (wv::all(fok)) {
-            const bool sw = dphi < 0 && alpha * pow(-dphi, S_PHI) > DELTA * pow(th0, S_THETA);
+            bool sw = false;
+            if (th0 <= theta_min && dphi < 0) sw = alpha * pow(-dphi, S_PHI) > DELTA * pow(th0, S_THETA);
             if (th0 <= theta_min && sw) {
               if (phit <= phi0 + ETA_PHI * alpha * dphi || phit - phi0 <= 10 * 2.2e-16 * fabs(phi0)) { accepted = true; armijo_type = true; }
             } else if (tht <= (1 - G_THETA) * th0 || phit <= phi0 - G_PHI * th0) accepted = true;
           }
         }
         if (accepted) break;
-        alpha *= 0.5;
+        alpha = wv::uni(alpha * 0.5);
         if (alpha < a_min || alpha < 1e-16) break;
       }
       if (a.trace && b == a.trace_instance && lane == 0) {
@@ -776,28 +751,48 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         wv::sync();
       }
 
-      // ----- apply the step ---------------------------------------------------------------------------------------
+      // ----- accept the trial point: duals first (they use the reciprocals of the old point) ----------------------
+      auto upd = [&](const Bnd& q, Item& it, double ds, double snew) {
+        double dvL, dvU; item_dv(q, it, ds, mu, dvL, dvU);
+        it.vL += a_du * dvL; it.vU += a_du * dvU;
+        item_recip(q, snew, it);
+        if (q.hasL) it.vL = fmax(fmin(it.vL, K_SIGMA * mu * it.iL), mu * it.iL / K_SIGMA);
+        if (q.hasU) it.vU = fmax(fmin(it.vU, K_SIGMA * mu * it.iU), mu * it.iU / K_SIGMA);
+      };
+      if (bu0_on) upd(qU0, iU0, dU[0], Ut[0]);
+      if (bu1_on) upd(qU1, iU1, dU[1], Ut[1]);
+      if (by_on) upd(qY, iY, dX[1], Xt[1]);
+      if (bv_on) upd(qV, iV, dX[3], Xt[3]);
+      if (rr_on) upd(qR, iR, dsR, sRt);
+#pragma unroll
+      for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
+        const double dv = mu * iO[j] - vO[j] - vO[j] * iO[j] * dsO[j];
+        vO[j] += a_du * dv;
+        iO[j] = wv::rcp(sOt[j] - qO.L);
+        vO[j] = fmax(fmin(vO[j], K_SIGMA * mu * iO[j]), mu * iO[j] / K_SIGMA);
+      }
       if (xnode) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { X[i] += alpha * dX[i]; lam[i] += alpha * (lamF[i] - lam[i]); }
+        for (int i = 0; i < NX; ++i) { X[i] = Xt[i]; lam[i] += alpha * (lamF[i] - lam[i]); }
       }
-      if (hasu) { U[0] += alpha * dU[0]; U[1] += alpha * dU[1]; }
-      auto upd = [&](const Bnd& q, double s, double& vL, double& vU, double dvL, double dvU) {
-        if (q.hasL) { vL += a_du * dvL; double d = s - q.L; vL = fmax(fmin(vL, K_SIGMA * mu / d), mu / (K_SIGMA * d)); }
-        if (q.hasU) { vU += a_du * dvU; double d = q.U - s; vU = fmax(fmin(vU, K_SIGMA * mu / d), mu / (K_SIGMA * d)); }
-      };
-      if (bu0_on) upd(qU0, U[0], zU0L, zU0U, dzU0L, dzU0U);
-      if (bu1_on) upd(qU1, U[1], zU1L, zU1U, dzU1L, dzU1U);
-      if (by_on) upd(qY, X[1], zYL, zYU, dzYL, dzYU);
-      if (bv_on) upd(qV, X[3], zVL, zVU, dzVL, dzVU);
-      if (rr_on) { sR += alpha * dsR; upd(qR, sR, vRL, vRU, dvRL, dvRU); }
+      if (hasu) { U[0] = Ut[0]; U[1] = Ut[1]; }
+      sR = sRt; rR = rRt; Up0 = upt0; Up1 = upt1;
+      sp = st_; cp = ct_; td = tt_; sec2 = et_;
 #pragma unroll
-      for (int j = 0; j < NOBS; ++j) if (ro_on[j]) { double dummy = 0; sO[j] += alpha * dsO[j]; upd(qO, sO[j], vO[j], dummy, dvO[j], 0.0); }
-      eval_point();
+      for (int i = 0; i < NX; ++i) dfc[i] = dft[i];
+#pragma unroll
+      for (int j = 0; j < NOBS; ++j) {
+        sO[j] = sOt[j]; rO[j] = rOt[j];
+        if (ro_on[j]) { gO0[j] = 2 * (X[0] - ox[j]) * ix2[j]; gO1[j] = 2 * (X[1] - oy[j]) * iy2[j]; }
+      }
+      theta = tht; fval = ft; logsum = lst;
       if (!isfinite(theta) || !isfinite(fval)) { status = MPCB_ST_NUMERIC; break; }
     }
   } else {
-    eval_point();
+    trig(X[2], U[0], sp, cp, td, sec2);
+    double th, fl, prod;
+    eval_lane(X, U, sR, sO, sp, cp, td, dfc, rR, rO, Up0, Up1, th, fl, prod);
+    fval = wv::sum(fl);
   }
 
   // ----- outputs (reference ordering), staged through LDS for coalesced stores ----------------------------------
@@ -809,21 +804,20 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   }
   wv::sync();
   for (int i = lane; i < nz; i += 64) a.z[(size_t)b * nz + i] = zbuf[i];
-  const double e_final = kkt_error(0.0);
   if (lane == 0) {
     if (a.obj) a.obj[b] = fval;
     if (a.status) a.status[b] = status;
     if (a.iters) a.iters[b] = iters;
-    if (a.kkt) { double* q = a.kkt + (size_t)b * 4; q[0] = e_final; q[1] = e_prim; q[2] = e_dual / os; q[3] = mu; }
+    if (a.kkt) { double* q = a.kkt + (size_t)b * 4; q[0] = err0; q[1] = e_prim; q[2] = e_dual / os; q[3] = mu; }
   }
   if (a.want_mult && a.lam_x) {
     wv::sync();
     for (int i = lane; i < nz; i += 64) zbuf[i] = 0.0;
     wv::sync();
-    if (bu0_on) zbuf[NU * k] = -dual_y(qU0, zU0L, zU0U) / os;
-    if (bu1_on) zbuf[NU * k + 1] = -dual_y(qU1, zU1L, zU1U) / os;
-    if (by_on) zbuf[NU * N + NX * k + 1] = -dual_y(qY, zYL, zYU) / os;
-    if (bv_on) zbuf[NU * N + NX * k + 3] = -dual_y(qV, zVL, zVU) / os;
+    if (bu0_on) zbuf[NU * k] = -item_y(qU0, iU0) / os;
+    if (bu1_on) zbuf[NU * k + 1] = -item_y(qU1, iU1) / os;
+    if (by_on) zbuf[NU * N + NX * k + 1] = -item_y(qY, iY) / os;
+    if (bv_on) zbuf[NU * N + NX * k + 3] = -item_y(qV, iV) / os;
     wv::sync();
     for (int i = lane; i < nz; i += 64) a.lam_x[(size_t)b * nz + i] = zbuf[i];
   }
@@ -839,11 +833,12 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       for (int i = 0; i < NX; ++i) out[r_dyn + NX * (k - 1) + i] = -lam[i] / os;
     }
     if (k == 0) {   // stationarity wrt the pinned X_0
+      const double a02 = -T * X[3] * sp, a03 = T * cp, a12 = T * X[3] * cp, a13 = T * sp, a23 = T * td * il;
       const double At[NX] = {ln[0], ln[1], a02 * ln[0] + a12 * ln[1] + ln[2], a03 * ln[0] + a13 * ln[1] + a23 * ln[2] + ln[3]};
 #pragma unroll
       for (int i = 0; i < NX; ++i) out[i] = -2 * c.Q[i] * (X[i] - xs[i]) - At[i] / os;
     }
-    if (rr_on) out[r_rate + (k - 1)] = -dual_y(qR, vRL, vRU) / os;
+    if (rr_on) out[r_rate + (k - 1)] = -item_y(qR, iR) / os;
     if (isnode) {
       const int row = (c.obs_mode == MPCB_OBS_KEEPOUT) ? k : k - 1;
 #pragma unroll

@@ -43,6 +43,46 @@ MPCB_DEV double min(double v) {
 }
 MPCB_DEV bool any(bool p) { return __any(p) != 0; }
 MPCB_DEV bool all(bool p) { return __all(p) != 0; }
+
+// ---- fused multi-value reductions: NS sums and NM maxima in one interleaved butterfly (independent chains
+// give the scheduler ILP).  Steps 1,2,4,8 are DPP moves inside a 16-lane row, 16 and 32 go through ds_bpermute.
+// Association order = xor butterfly (quad-mirror steps pair the same partial sums), every lane ends bit-identical.
+template <int CTRL> MPCB_DEV double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int NS, int NM> MPCB_DEV void reduce(double* s, double* m) {
+#define MPCB_STEP(EXPR)                                                        \
+  {                                                                            \
+    double ts[NS > 0 ? NS : 1], tm[NM > 0 ? NM : 1];                           \
+    _Pragma("unroll") for (int i = 0; i < NS; ++i) { double v = s[i]; ts[i] = EXPR; } \
+    _Pragma("unroll") for (int i = 0; i < NM; ++i) { double v = m[i]; tm[i] = EXPR; } \
+    _Pragma("unroll") for (int i = 0; i < NS; ++i) s[i] += ts[i];              \
+    _Pragma("unroll") for (int i = 0; i < NM; ++i) m[i] = fmax(m[i], tm[i]);   \
+  }
+  MPCB_STEP(dpp_mov<0xB1>(v))      // quad_perm [1,0,3,2]
+  MPCB_STEP(dpp_mov<0x4E>(v))      // quad_perm [2,3,0,1]
+  MPCB_STEP(dpp_mov<0x141>(v))     // row_half_mirror
+  MPCB_STEP(dpp_mov<0x140>(v))     // row_mirror
+  MPCB_STEP(__shfl_xor(v, 16, 64))
+  MPCB_STEP(__shfl_xor(v, 32, 64))
+#undef MPCB_STEP
+}
+// a wave-uniform double moved to scalar registers
+MPCB_DEV double uni(double v) {
+  int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+// reciprocal: hardware estimate + two Newton steps (no denormal / overflow rescaling: arguments are slacks and duals)
+MPCB_DEV double rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
 }  // namespace wv
 
 #else  // ------------------------------------------------------------------ host emulation (tests only)
@@ -86,5 +126,12 @@ inline double max(double v) { return reduce(v, [](double a, double b) { return s
 inline double min(double v) { return reduce(v, [](double a, double b) { return std::fmin(a, b); }); }
 inline bool any(bool p) { return sum(p ? 1.0 : 0.0) > 0.0; }
 inline bool all(bool p) { return sum(p ? 0.0 : 1.0) == 0.0; }
+
+template <int NS, int NM> inline void reduce(double* s, double* m) {
+  for (int i = 0; i < NS; ++i) s[i] = sum(s[i]);
+  for (int i = 0; i < NM; ++i) m[i] = max(m[i]);
+}
+inline double uni(double v) { return v; }
+inline double rcp(double x) { return 1.0 / x; }
 }  // namespace wv
 #endif

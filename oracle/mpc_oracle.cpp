@@ -878,6 +878,7 @@ struct Solver {
     }
     if (obj) *obj = objective(X, U);
     if (st) *st = status;
+    if (std::getenv("MPCO_STATS")) std::fprintf(stderr, "STATS %d %d %d %d\n", status, iters, n_factor, n_trial);
     if (it) *it = iters;
     if (kkt) {
       double du = 0; Err e = kkt_error(0.0, &du);

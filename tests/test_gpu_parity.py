@@ -1,8 +1,11 @@
 """GPU parity tests proper: the HIP path (libmpcbatch.so through its C ABI) against the CPU oracle, the committed
 golden vectors and solver-independent KKT certificates.  Run with `-m gpu` on the MI355X box.
 
-Tolerance: trajectory L-inf <= 1e-6 between the HIP path and the oracle on instances both solve
-(north_star asks <= 1e-4 versus IPOPT; versus IPOPT itself parity is unpinned — casadi is absent)."""
+Tolerance: trajectory L-inf <= 1e-5 between the HIP path and the oracle on instances both solve (north_star asks
+<= 1e-4 versus IPOPT; versus IPOPT itself parity is unpinned — casadi is absent).  Why not tighter:
+both sides stop as soon as IPOPT's SCALED error is <= tol = 1e-8; the objective scaling is ~1e-4 and the weakest
+curvature (Q_x = 10) then leaves x free within ~1e-6, so two runs whose rounding differs stop at different points of
+that ball.  test_tight_tolerance_agreement shows the two paths agree to 1e-8 when tol is tightened."""
 import os
 
 import numpy as np
@@ -13,7 +16,7 @@ from mpc_motion_planning_amd.solver import default_config
 
 pytestmark = pytest.mark.gpu
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "solutions.npz"))
-TOL_Z = 1e-6
+TOL_Z = 1e-5
 
 
 def agree(gpu, ref, tol=TOL_Z, min_same_status=1.0):
@@ -82,6 +85,14 @@ def test_random_c3_predicted_obstacles_against_oracle(gpu_solver_factory, oracle
     g = gpu_solver_factory(cfg2).solve_batch(x0[:64], xs[:64], o0[:64, :2])
     r = oracle_mod.solve(cfg2, x0[:64], xs[:64], o0[:64, :2])
     agree(g, r, min_same_status=0.98)
+
+
+def test_tight_tolerance_agreement(gpu_solver_factory, oracle_mod):
+    cfg = default_config(N=30, n_obs=1); cfg.tol = 1e-11
+    x0, xs, obs = scenes.sample_c2(256, seed=12)
+    g = gpu_solver_factory(cfg).solve_batch(x0, xs, obs); r = oracle_mod.solve(cfg, x0, xs, obs)
+    both = (g["status"] == 0) & (r["status"] == 0)
+    assert both.sum() >= 150 and np.abs(g["z"][both] - r["z"][both]).max() <= 1e-8
 
 
 def test_variants_horizons_modes(gpu_solver_factory, oracle_mod):
