@@ -37,7 +37,7 @@ def algorithmic_bytes_per_solve(nx, nz, n_obs_values):
     return 8 * (2 * nx + nz + n_obs_values + nz) + 16
 
 
-def cpu_baseline(cfg, x0, xs, obs, min_seconds=2.0):
+def cpu_baseline(cfg, x0, xs, obs, min_seconds=1.5):
     """The CPU oracle (oracle/mpc_oracle.cpp, same NLP, same algorithm, OpenMP over the batch) timed on this box's
     host cores on a bounded sample of the same workload.  Reported next to the GPU number; CasADi+IPOPT cannot be
     timed (not installed here nor on the GPU box, no network: SURVEY.md §0 F2)."""
@@ -53,7 +53,7 @@ def cpu_baseline(cfg, x0, xs, obs, min_seconds=2.0):
         r = oracle.solve(cfg, x0[:n], xs[:n], obs[:n], threads=cores, want_multipliers=False)
         solved += int((r["status"] == 0).sum()); reps += 1
         dt = time.perf_counter() - t0
-        if dt >= min_seconds or reps >= 8:
+        if dt >= min_seconds:          # ~16 threads x 1.5 s = about 25 core-seconds of CPU work
             break
     return {"value": solved / dt, "unit": "solves/s", "cores": cores, "kind": "port",
             "sample": "%d x first %d instances of the step's batch, OpenMP over instances, %.1f s wall (%.0f core-s)" % (reps, n, dt, dt * cores),

@@ -158,13 +158,20 @@ int mpcb_solve_device(mpcb_handle* h, int32_t B,
                       double* d_lam_g, double* d_lam_x, int32_t sync);
 
 /* Closed loop on the device: `steps` receding-horizon iterations of  solve -> apply U_0 with the plant
- * x0 <- x0 + T f(x0,U_0) -> shift warm start -> advance obstacles   (main_cbf_kin_c_sim.py:87-123,16-26;
+ * x0 <- x0 + T f(x0,U_0) -> shift warm start [-> advance obstacles]   (main_cbf_kin_c_sim.py:87-123,16-26;
  * main_cbf_kin_c_sim_pre.py:98-106).  Host pointers.
- *   obs_state [B, n_obs, 6] in/out (constant-velocity obstacles, Obs_prediction.py:27-30; v = 0 keeps them static)
- *   predict   1: rows use the predicted position per node (kin_pre.py:239-247); 0: rows use the current position
+ *   obs_state [B, n_obs, 6] in/out
+ *   obs_motion  MPCB_OBSMOVE_STATIC    obstacles never move, rows use obs_state as is      (main_cbf_kin_c_sim.py:55,99)
+ *               MPCB_OBSMOVE_PREDICTED constant-velocity obstacles (Obs_prediction.py:27-30): predicted over the horizon
+ *                                      for every solve, advanced one step per MPC step       (main_cbf_kin_c_sim_pre.py:98-106;
+ *                                      the reference advances only its first obstacle, here all of them)
+ *               MPCB_OBSMOVE_CURRENT   advanced one step per MPC step, rows use the current position at every node
  *   x_hist [B, steps+1, nx], u_hist [B, steps, 2] (may be NULL), status_hist [B, steps], iters_hist [B, steps] */
+#define MPCB_OBSMOVE_STATIC    0
+#define MPCB_OBSMOVE_PREDICTED 1
+#define MPCB_OBSMOVE_CURRENT   2
 int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps,
-                     const double* x0, const double* xs, double* obs_state, int32_t predict,
+                     const double* x0, const double* xs, double* obs_state, int32_t obs_motion,
                      double* x_hist, double* u_hist, int32_t* status_hist, int32_t* iters_hist);
 
 /* device memory helpers so that Python (ctypes, no torch) can keep batches resident */

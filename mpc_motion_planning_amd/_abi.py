@@ -14,6 +14,7 @@ MODEL_KIN, MODEL_DYN = 0, 1
 OBS_KEEPOUT, OBS_DCBF = 0, 1
 OBSIN_STATIC, OBSIN_PREDICTED = 0, 1
 MU_MONOTONE, MU_ADAPTIVE = 0, 1
+OBSMOVE_STATIC, OBSMOVE_PREDICTED, OBSMOVE_CURRENT = 0, 1, 2
 NX_MAX, NU, NOBS_MAX, N_MAX = 6, 2, 8, 63
 
 _d = C.c_double

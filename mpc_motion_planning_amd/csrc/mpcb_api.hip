@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64, MPCB_WAVES_PER_SIMD) void mpcb_kernel_kin(const
 //   main_cbf_kin_c_sim.py:16-26 (shift_movement), main_cbf_kin_c_sim_pre.py:106 (obstacle advance)
 __global__ void mpcb_advance_kin(int B, int N, int nz, int n_obs, double T, double veh_l, const double* __restrict__ z,
                                  double* __restrict__ x0, double* __restrict__ z0, double* __restrict__ obs,
-                                 double* __restrict__ x_hist, double* __restrict__ u_hist, int step, int steps) {
+                                 double* __restrict__ x_hist, double* __restrict__ u_hist, int step, int steps, int move_obs) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const double* zb = z + (size_t)b * nz;
@@ -51,7 +51,7 @@ __global__ void mpcb_advance_kin(int B, int N, int nz, int n_obs, double T, doub
   for (int i = 0; i < N; ++i) { int s = (i + 1 < N) ? i + 1 : N - 1; w[2 * i] = zb[2 * s]; w[2 * i + 1] = zb[2 * s + 1]; }
   for (int i = 0; i <= N; ++i) { int s = (i + 1 <= N) ? i + 1 : N; for (int q = 0; q < 4; ++q) w[2 * N + 4 * i + q] = zb[2 * N + 4 * s + q]; }
   // obstacles move one step with constant velocity and heading (Obs_prediction.py:27-30)
-  for (int j = 0; j < n_obs; ++j) {
+  for (int j = 0; move_obs && j < n_obs; ++j) {
     double* o = obs + ((size_t)b * n_obs + j) * 6;
     o[0] += o[3] * cos(o[2]) * T; o[1] += o[3] * sin(o[2]) * T;
   }
@@ -401,11 +401,13 @@ int mpcb_solve(mpcb_handle* h, int32_t B, const double* x0, const double* xs, co
   return MPCB_OK;
 }
 
-int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps, const double* x0, const double* xs, double* obs_state, int32_t predict,
+int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps, const double* x0, const double* xs, double* obs_state, int32_t obs_motion,
                      double* x_hist, double* u_hist, int32_t* status_hist, int32_t* iters_hist) {
   if (!h) return MPCB_E_INVALID;
   if (B < 0 || steps < 0 || !x0 || !xs) return fail(h, MPCB_E_INVALID, "B < 0, steps < 0 or a required pointer is NULL");
   if (h->cfg.n_obs > 0 && !obs_state) return fail(h, MPCB_E_INVALID, "n_obs = %d but obs_state is NULL", h->cfg.n_obs);
+  if (obs_motion < MPCB_OBSMOVE_STATIC || obs_motion > MPCB_OBSMOVE_CURRENT) return fail(h, MPCB_E_INVALID, "unknown obs_motion %d", obs_motion);
+  const int predict = obs_motion == MPCB_OBSMOVE_PREDICTED;
   if (B == 0 || steps == 0) return MPCB_OK;
   HIP_TRY(h, hipSetDevice(h->device));
   const int nx = h->nx, nz = h->nz, N = h->cfg.N, no = h->cfg.n_obs;
@@ -446,7 +448,7 @@ int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps, const double* x0,
     HIP_TRY(h, hipMemcpy2DAsync(d_st + t, (size_t)steps * 4, d_stc, 4, 4, B, hipMemcpyDeviceToDevice, s));
     HIP_TRY(h, hipMemcpy2DAsync(d_it + t, (size_t)steps * 4, d_itc, 4, 4, B, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(mpcb_advance_kin, dim3((B + 127) / 128), dim3(128), 0, s, B, N, nz, no, h->cfg.T, h->cfg.veh_l, d_z, d_x0, d_z0,
-                       d_obs, d_xh, d_uh, t, steps);
+                       d_obs, d_xh, d_uh, t, steps, obs_motion != MPCB_OBSMOVE_STATIC ? 1 : 0);
     HIP_TRY(h, hipGetLastError());
   }
   if (x_hist) HIP_TRY(h, hipMemcpyAsync(x_hist, d_xh, (size_t)B * (steps + 1) * nx * 8, hipMemcpyDeviceToHost, s));

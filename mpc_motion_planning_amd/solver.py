@@ -131,8 +131,11 @@ class BatchSolver:
             out["lam_g"] = lam_g; out["lam_x"] = lam_x
         return out
 
-    def closed_loop(self, x0, xs, obs_state=None, steps=80, predict=False):
-        """Receding-horizon loop on the device (main_cbf_kin_c_sim.py:87-123).  Returns dict(x_hist, u_hist, status, iters, obs_state)."""
+    def closed_loop(self, x0, xs, obs_state=None, steps=80, obs_motion=_abi.OBSMOVE_STATIC):
+        """Receding-horizon loop on the device (main_cbf_kin_c_sim.py:87-123).  obs_motion: OBSMOVE_STATIC (obstacles fixed,
+        main_cbf_kin_c_sim.py), OBSMOVE_PREDICTED (constant-velocity obstacles predicted per solve and advanced per step,
+        main_cbf_kin_c_sim_pre.py), OBSMOVE_CURRENT (advanced, no prediction).
+        Returns dict(x_hist, u_hist, status, iters, obs_state)."""
         x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, dtype=np.float64)))
         xs = np.ascontiguousarray(np.atleast_2d(np.asarray(xs, dtype=np.float64)))
         B = x0.shape[0]
@@ -141,7 +144,7 @@ class BatchSolver:
             ob = np.array(obs_state, dtype=np.float64).reshape(B, self.cfg.n_obs, 6).copy()
         xh = np.empty((B, steps + 1, self.nx)); uh = np.empty((B, steps, 2))
         st = np.empty((B, steps), np.int32); it = np.empty((B, steps), np.int32)
-        check(lib().mpcb_closed_loop(self._h, B, steps, dptr(x0), dptr(xs), dptr(ob), 1 if predict else 0, dptr(xh), dptr(uh),
+        check(lib().mpcb_closed_loop(self._h, B, steps, dptr(x0), dptr(xs), dptr(ob), int(obs_motion), dptr(xh), dptr(uh),
                                      iptr(st), iptr(it)), self._h)
         return dict(x_hist=xh, u_hist=uh, status=st, iters=it, obs_state=ob)
 

@@ -219,7 +219,7 @@ def test_closed_loop_on_device_matches_host_loop(gpu_solver_factory):
     x0[:, 0] = np.minimum(x0[:, 0], 10.0)
     obs = obs.copy(); obs[:, :, 3] = 6.0
     for predict in (False, True):
-        dev = bs.closed_loop(x0, xs, obs, steps=steps, predict=predict)
+        dev = bs.closed_loop(x0, xs, obs, steps=steps, obs_motion=_abi.OBSMOVE_PREDICTED if predict else _abi.OBSMOVE_CURRENT)
         good = (dev["status"] == 0).all(axis=1)          # instances that solve at every step (others feed failed iterates forward)
         assert good.sum() >= 8
         xc = x0.copy(); oc = obs.copy(); z0 = np.zeros((B, 184)); xh = [xc.copy()]
@@ -235,3 +235,17 @@ def test_closed_loop_on_device_matches_host_loop(gpu_solver_factory):
             xh.append(xc.copy())
         assert np.abs(np.stack(xh, axis=1)[good] - dev["x_hist"][good]).max() <= 1e-7
         assert np.abs(oc - dev["obs_state"]).max() <= 1e-12
+
+
+def test_driver_counterparts_run(tmp_path):
+    """The shipped counterparts of main_cbf_kin_c_sim.py / _pre.py / main_kin_s_sim.py: host loop == device loop, the
+    ego passes the obstacle without entering the keep-out ellipse."""
+    from mpc_motion_planning_amd.sim import main_cbf_kin_c_sim, main_cbf_kin_c_sim_pre, main_kin_s_sim
+    xh, uh = main_cbf_kin_c_sim.main(["--sim-time", "3.0"])
+    xd, ud = main_cbf_kin_c_sim.main(["--sim-time", "3.0", "--device-loop"])
+    assert xh.shape == (31, 4) and np.abs(xh - xd).max() <= 1e-6 and np.abs(uh - ud).max() <= 1e-6
+    xp, up, op = main_cbf_kin_c_sim_pre.main(["--sim-time", "2.0"])
+    h = ((xp[:, 0] - op[:, 0]) / 5.8) ** 2 + ((xp[:, 1] - op[:, 1]) / 2.3) ** 2 - 1
+    assert h.min() >= -1e-6 and xp[-1, 0] > 30
+    z = main_kin_s_sim.main()
+    assert z.shape == (184, 1)
