@@ -1,9 +1,9 @@
 """Dynamic-bicycle MPC (6 states, nonlinear tyre) — surface of
 CasaDi_MPC_Optimize_Multishoot/MPC_CBF_optimize_dyn.py.
 
-Status: the problem description, the model function `f` and the bounds are here; the device kernel for the
-6-state model is not built yet, so `solver(...)` raises MpcbError(MPCB_E_UNSUPPORTED)
-from mpcb_create.  Two defects of the reference file are not reproduced: it reads vehicle_params['Veh_w'] while
+Solved on the device by mpcb_kernel_dyn (closed-form tyre-model derivatives, 10x10 stage block).  The obstacle row is
+posed as h >= 1 instead of the reference's sqrt(h) >= 1 (same feasible set and KKT points, no NaN inside the ellipse).
+Two defects of the reference file are not reproduced: it reads vehicle_params['Veh_w'] while
 the YAML key is 'Veh_W' (ref :45), and its lbg/ubg lists are interleaved one stage off its g rows (ref :112-129
 vs :215-231); `initialize_constraints` below returns bounds aligned with g.
 """

@@ -12,7 +12,7 @@
 #include <string>
 #include <vector>
 
-#include "mpcb_kernel.h"
+#include "mpcb_kernel_dyn.h"
 
 #ifndef MPCB_WAVES_PER_SIMD
 #define MPCB_WAVES_PER_SIMD 1
@@ -27,6 +27,12 @@ template <int NOBS>
 __global__ __launch_bounds__(64, MPCB_WAVES_PER_SIMD) void mpcb_kernel_kin(const MpcbKArgs a) {
   extern __shared__ __attribute__((aligned(16))) double mpcb_lds[];
   mpcb_solve_kin<NOBS>(a, (int)blockIdx.x, mpcb_lds);
+}
+
+template <int NOBS>
+__global__ __launch_bounds__(64, MPCB_WAVES_PER_SIMD) void mpcb_kernel_dyn(const MpcbKArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double mpcb_lds[];
+  mpcb_solve_dyn<NOBS>(a, (int)blockIdx.x, mpcb_lds);
 }
 
 // closed-loop helper: plant step with the first control, warm-start shift, obstacle advance.
@@ -114,21 +120,28 @@ int check_cfg(mpcb_handle* h, const mpcb_config* c) {
   if (!(c->T > 0) || !(c->tol > 0) || c->max_iter < 0 || !(c->mu_init > 0)) return fail(h, MPCB_E_INVALID, "T, tol, mu_init must be > 0 and max_iter >= 0");
   if (!(c->veh_l > 0)) return fail(h, MPCB_E_INVALID, "veh_l must be > 0");
   for (int i = 0; i < 2; ++i) if (!(c->R[i] > 0)) return fail(h, MPCB_E_INVALID, "R must be positive");
-  if (c->model == MPCB_MODEL_DYN) return fail(h, MPCB_E_UNSUPPORTED, "the dynamic-bicycle kernel is not built yet (DESIGN.md, scope row f3)");
   if (c->obs_mode == MPCB_OBS_DCBF && std::fabs(c->gamma - 1.0) > 1e-12)
     return fail(h, MPCB_E_UNSUPPORTED, "discrete-CBF rows are implemented for gamma = 1 only (the reference's value, kin.py:235)");
   if (c->obs_mode != MPCB_OBS_KEEPOUT && c->obs_mode != MPCB_OBS_DCBF) return fail(h, MPCB_E_INVALID, "unknown obs_mode %d", c->obs_mode);
   if (c->mu_strategy != MPCB_MU_MONOTONE) return fail(h, MPCB_E_UNSUPPORTED, "only MPCB_MU_MONOTONE is implemented on the device");
-  // kinematic kernel: boxes on y and vx only, rate row on the steering angle only, rows not interleaved
   if (std::isfinite(c->x_lo[0]) || std::isfinite(c->x_hi[0]) || std::isfinite(c->x_lo[2]) || std::isfinite(c->x_hi[2]))
-    return fail(h, MPCB_E_UNSUPPORTED, "kinematic kernel: state boxes are supported on y and vx (kin.py:97-105)");
-  if (std::isfinite(c->du_lo[1]) || std::isfinite(c->du_hi[1]))
-    return fail(h, MPCB_E_UNSUPPORTED, "kinematic kernel: rate rows are supported on the steering angle only (kin.py:216-217)");
-  if (c->rate_interleaved) return fail(h, MPCB_E_UNSUPPORTED, "kinematic kernel: rate rows form one block (kin.py:211-216)");
+    return fail(h, MPCB_E_UNSUPPORTED, "state boxes are supported on y, vx (and vy for the dynamic model) (kin.py:97-105, dyn.py:97-110)");
+  if (c->model == MPCB_MODEL_KIN) {
+    // kinematic kernel: rate row on the steering angle only, rows not interleaved
+    if (std::isfinite(c->du_lo[1]) || std::isfinite(c->du_hi[1]))
+      return fail(h, MPCB_E_UNSUPPORTED, "kinematic kernel: rate rows are supported on the steering angle only (kin.py:216-217)");
+    if (c->rate_interleaved) return fail(h, MPCB_E_UNSUPPORTED, "kinematic kernel: rate rows form one block (kin.py:211-216)");
+  } else {
+    if (std::isfinite(c->x_lo[5]) || std::isfinite(c->x_hi[5])) return fail(h, MPCB_E_UNSUPPORTED, "dynamic kernel: no box on the yaw rate (dyn.py:109-110)");
+    if (!(c->veh_m > 0) || !(c->veh_Iz > 0) || !(c->aopt_f > 0) || !(c->aopt_r > 0)) return fail(h, MPCB_E_INVALID, "vehicle / tyre parameters must be positive");
+    if (!(c->x_lo[3] >= 0)) return fail(h, MPCB_E_INVALID, "dynamic model needs vx_min >= 0 (the tyre model divides by vx, dyn.py:156-157)");
+  }
   return MPCB_OK;
 }
 
-size_t lds_bytes(const mpcb_config& c, int nz) { return (size_t)mpcbk::layout_kin(c.N, nz).total * sizeof(double); }
+size_t lds_bytes(const mpcb_config& c, int nz) {
+  return (size_t)(c.model == MPCB_MODEL_DYN ? mpcbk::layout_dyn(c.N).total : mpcbk::layout_kin(c.N, nz).total) * sizeof(double);
+}
 
 int launch_solve(mpcb_handle* h, const MpcbKArgs& a) {
   const size_t lds = lds_bytes(h->cfg, h->nz);
@@ -146,11 +159,22 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a) {
       HIP_TRY(h, hipFuncSetAttribute((const void*)mpcb_kernel_kin<NOBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL(mpcb_kernel_kin<NOBS>, grid, block, lds, h->stream, a);                                 \
   } while (0)
-  if (n == 0) LAUNCH(0);
+#define LAUNCH_DYN(NOBS)                                                                                       \
+  do {                                                                                                         \
+    if (lds > 48 * 1024)                                                                                       \
+      HIP_TRY(h, hipFuncSetAttribute((const void*)mpcb_kernel_dyn<NOBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(mpcb_kernel_dyn<NOBS>, grid, block, lds, h->stream, a);                                 \
+  } while (0)
+  if (h->cfg.model == MPCB_MODEL_DYN) {
+    if (n <= 1) LAUNCH_DYN(1);
+    else if (n <= 3) LAUNCH_DYN(3);
+    else LAUNCH_DYN(8);
+  } else if (n == 0) LAUNCH(0);
   else if (n == 1) LAUNCH(1);
   else if (n <= 3) LAUNCH(3);
   else LAUNCH(8);
 #undef LAUNCH
+#undef LAUNCH_DYN
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipEventRecord(e1, h->stream));
   h->ev.emplace_back(e0, e1);

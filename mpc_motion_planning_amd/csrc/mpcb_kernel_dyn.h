@@ -1,0 +1,859 @@
+// mpcb_kernel_dyn.h — the batched MPC solve for the 6-state dynamic bicycle with the nonlinear tyre model.
+//
+// What it replaces: the IPOPT solve of the NLP of CasaDi_MPC_Optimize_Multishoot/MPC_CBF_optimize_dyn.py
+// (model :156-170, cost :189-225, dynamics rows :226-228, rate rows on both controls :229-231, obstacle rows at
+// all N+1 nodes :238-243, boxes :85-110).  Same algorithm and wave mapping as mpcb_kernel.h (lane k = node k for
+// everything lane-parallel); the differences are sizes and the model:
+//   * nx = 6, augmented state 8, stage block 10x10 = 100 entries -> TWO entries per lane in the Riccati sweep,
+//     M is exchanged through LDS (3 LDS round trips per stage);
+//   * closed-form first and second derivatives of the tyre model (checked against the oracle's forward-mode AD);
+//   * boxes on y, vx, vy; rate rows on steering AND acceleration; obstacle rows of the form h >= obs_hmin.
+// The reference's own bounds lists for this model are mis-aligned with its rows; the rows here are
+// the aligned ones.  The obstacle row is written h >= hmin (hmin = 1) instead of the reference's sqrt(h) >= 1: same
+// feasible set and same KKT points, no NaN inside the ellipse.
+#pragma once
+
+#include "mpcb_kernel.h"
+
+namespace mpcbk {
+
+enum DynEnt {
+  DE_ZERO = 0, DE_ONE, DE_T,
+  DE_A02, DE_A03, DE_A04, DE_A12, DE_A13, DE_A14, DE_A34, DE_A35, DE_A43, DE_A44, DE_A45, DE_A53, DE_A54, DE_A55,
+  DE_B4, DE_B5,
+  DE_D0, DE_D1, DE_D2, DE_D3, DE_D4, DE_D5,
+  DE_G0, DE_G1, DE_G2, DE_G3, DE_G4, DE_G5, DE_G6, DE_G7, DE_G8, DE_G9,
+  DE_H00, DE_H01, DE_H11, DE_H22, DE_H23, DE_H24, DE_H33, DE_H34, DE_H35, DE_H44, DE_H45, DE_H55,
+  DE_H38, DE_H48, DE_H58, DE_H88, DE_H99, DE_H66, DE_H77, DE_H68, DE_H79,
+  DYN_NENT
+};
+
+struct LayoutDyn { int ld, ent, Pst, pst, Kst, kff, W, q, M, m, filt, zbuf, total; };
+MPCB_HD LayoutDyn layout_dyn(int N) {
+  LayoutDyn L;
+  const int N1 = N + 1, NA = 8, NW = 10;
+  L.ld = N1 | 1;
+  int o = 0;
+  L.ent = o; o += DYN_NENT * L.ld;
+  L.Pst = o; o += N1 * NA * NA;
+  L.pst = o; o += N1 * NA;
+  L.Kst = o; o += N1 * 2 * NA;
+  L.kff = o; o += N1 * 2;
+  L.W = o; o += NW * NA;
+  L.q = o; o += NW;
+  L.M = o; o += NW * NW;
+  L.m = o; o += NW + 2;
+  L.filt = o; o += 2 * FILTER_MAX;
+  L.zbuf = L.Pst;
+  L.total = o;
+  return L;
+}
+
+// everything the model needs at one node: trig of heading and steering, slip angles, tyre forces and their derivatives
+struct DynEval { double sp, cp, sd, cd, ivx, pf, pr, Ff, Ff1, Ff2, Fr, Fr1, Fr2; };
+MPCB_DEV void dyn_eval(const mpcb_config& c, const double* X, const double* U, DynEval& e) {
+  sincos_b(X[2], e.sp, e.cp);
+  sincos_b(U[0], e.sd, e.cd);
+  e.ivx = wv::rcp(X[3]);
+  e.pf = X[4] + c.veh_lf * X[5];
+  e.pr = X[4] - c.veh_lr * X[5];
+  const double af = U[0] - e.pf * e.ivx, ar = -e.pr * e.ivx;
+  const double cF = c.Fymax_f * 2.0 * c.aopt_f, cR = c.Fymax_r * 2.0 * c.aopt_r;
+  const double a2f = c.aopt_f * c.aopt_f, a2r = c.aopt_r * c.aopt_r;
+  const double qf = wv::rcp(a2f + af * af), qr = wv::rcp(a2r + ar * ar);
+  e.Ff = -cF * af * qf;                                   // F_cf = -C_f alpha_f, C_f = cF / (aopt^2 + alpha^2)   dyn.py:158-161
+  e.Ff1 = -cF * (a2f - af * af) * qf * qf;
+  e.Ff2 = 2.0 * cF * af * (3.0 * a2f - af * af) * qf * qf * qf;
+  e.Fr = -cR * ar * qr;
+  e.Fr1 = -cR * (a2r - ar * ar) * qr * qr;
+  e.Fr2 = 2.0 * cR * ar * (3.0 * a2r - ar * ar) * qr * qr * qr;
+}
+// F = X + T f(X, U)                                                                          dyn.py:165-170,227
+MPCB_DEV void dyn_F(const mpcb_config& c, const double* X, const double* U, const DynEval& e, double* F) {
+  const double T = c.T, vx = X[3], vy = X[4], r = X[5];
+  F[0] = X[0] + T * (vx * e.cp - vy * e.sp);
+  F[1] = X[1] + T * (vx * e.sp + vy * e.cp);
+  F[2] = X[2] + T * r;
+  F[3] = X[3] + T * (U[1] + r * vy);
+  F[4] = X[4] + T * (-r * vx + (2.0 / c.veh_m) * (e.Ff * e.cd + e.Fr));
+  F[5] = X[5] + T * ((2.0 / c.veh_Iz) * (c.veh_lf * e.Ff - c.veh_lr * e.Fr));
+}
+struct DynJac { double a02, a03, a04, a12, a13, a14, a34, a35, a43, a44, a45, a53, a54, a55, b4, b5; };
+MPCB_DEV void dyn_jac(const mpcb_config& c, const double* X, const DynEval& e, DynJac& J) {
+  const double T = c.T, vx = X[3], vy = X[4], r = X[5], k4 = 2.0 / c.veh_m, k5 = 2.0 / c.veh_Iz, lf = c.veh_lf, lr = c.veh_lr;
+  const double i2 = e.ivx * e.ivx;
+  const double afx = e.pf * i2, afy = -e.ivx, afr = -lf * e.ivx, arx = e.pr * i2, ary = -e.ivx, arr = lr * e.ivx;
+  J.a02 = T * (-vx * e.sp - vy * e.cp); J.a03 = T * e.cp; J.a04 = -T * e.sp;
+  J.a12 = T * (vx * e.cp - vy * e.sp); J.a13 = T * e.sp; J.a14 = T * e.cp;
+  J.a34 = T * r; J.a35 = T * vy;
+  J.a43 = T * (-r + k4 * (e.Ff1 * afx * e.cd + e.Fr1 * arx));
+  J.a44 = 1.0 + T * k4 * (e.Ff1 * afy * e.cd + e.Fr1 * ary);
+  J.a45 = T * (-vx + k4 * (e.Ff1 * afr * e.cd + e.Fr1 * arr));
+  J.b4 = T * k4 * (e.Ff1 * e.cd - e.Ff * e.sd);
+  J.a53 = T * k5 * (lf * e.Ff1 * afx - lr * e.Fr1 * arx);
+  J.a54 = T * k5 * (lf * e.Ff1 * afy - lr * e.Fr1 * ary);
+  J.a55 = 1.0 + T * k5 * (lf * e.Ff1 * afr - lr * e.Fr1 * arr);
+  J.b5 = T * k5 * lf * e.Ff1;
+}
+// sum_a lam_a T d2 f_a: entries over (phi=2, vx=3, vy=4, r=5, delta=8 in stage numbering)
+struct DynHess { double h22, h23, h24, h33, h34, h35, h44, h45, h55, h38, h48, h58, h88; };
+MPCB_DEV void dyn_hess(const mpcb_config& c, const double* X, const DynEval& e, const double* l, DynHess& H) {
+  const double T = c.T, vx = X[3], vy = X[4], k4 = 2.0 / c.veh_m, k5 = 2.0 / c.veh_Iz, lf = c.veh_lf, lr = c.veh_lr;
+  const double i2 = e.ivx * e.ivx, i3 = i2 * e.ivx;
+  const double af[3] = {e.pf * i2, -e.ivx, -lf * e.ivx}, ar[3] = {e.pr * i2, -e.ivx, lr * e.ivx};   // d alpha / d(vx, vy, r)
+  // second derivatives of alpha: (vx,vx), (vx,vy), (vx,r); all others zero
+  const double afxx = -2.0 * e.pf * i3, afxy = i2, afxr = lf * i2, arxx = -2.0 * e.pr * i3, arxy = i2, arxr = -lr * i2;
+  auto G = [&](int z, int w, double azw_f, double azw_r, double extra4) {
+    const double gf = e.Ff2 * af[z] * af[w] + e.Ff1 * azw_f, gr = e.Fr2 * ar[z] * ar[w] + e.Fr1 * azw_r;
+    return T * (l[4] * (k4 * (e.cd * gf + gr) + extra4) + l[5] * k5 * (lf * gf - lr * gr));
+  };
+  H.h22 = T * (l[0] * (-vx * e.cp + vy * e.sp) + l[1] * (-vx * e.sp - vy * e.cp));
+  H.h23 = T * (-l[0] * e.sp + l[1] * e.cp);
+  H.h24 = T * (-l[0] * e.cp - l[1] * e.sp);
+  H.h33 = G(0, 0, afxx, arxx, 0.0);
+  H.h34 = G(0, 1, afxy, arxy, 0.0);
+  H.h35 = G(0, 2, afxr, arxr, -1.0);
+  H.h44 = G(1, 1, 0.0, 0.0, 0.0);
+  H.h45 = G(1, 2, 0.0, 0.0, 0.0) + T * l[3];
+  H.h55 = G(2, 2, 0.0, 0.0, 0.0);
+  const double cz = T * (l[4] * k4 * (-e.sd * e.Ff1 + e.cd * e.Ff2) + l[5] * k5 * lf * e.Ff2);
+  H.h38 = cz * af[0]; H.h48 = cz * af[1]; H.h58 = cz * af[2];
+  H.h88 = T * (l[4] * k4 * (e.Ff2 * e.cd - 2.0 * e.Ff1 * e.sd - e.Ff * e.cd) + l[5] * k5 * lf * e.Ff2);
+}
+
+}  // namespace mpcbk
+
+template <int NOBS>
+MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
+  using namespace mpcbk;
+  constexpr int NX = 6, NA = 8, NW = 10, NOB = NOBS > 0 ? NOBS : 1, NSLOT = 2;
+  const mpcb_config& c = a.cfg;
+  const int N = c.N, lane = wv::lane(), k = lane;
+  const int nz = a.nz, nobs = c.n_obs;
+  const LayoutDyn L = layout_dyn(N);
+  const int ld = L.ld;
+  double* ent = lds + L.ent;
+  const double T = c.T;
+
+  const bool isnode = k <= N, hasu = k < N, xnode = k >= 1 && k <= N, xcost = k >= 1 && k < N;
+  const double* gx0 = a.x0 + (size_t)b * NX;
+  const double* gxs = a.xs + (size_t)b * NX;
+  double xs[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xs[i] = gxs[i];
+
+  const int last_row = c.obs_terminal ? N : N - 1;
+  bool obs_node; int ostep;
+  if (c.obs_mode == MPCB_OBS_KEEPOUT) { obs_node = k <= last_row; ostep = k; }
+  else { obs_node = k >= 1 && k - 1 <= last_row; ostep = k - 1; }
+  obs_node = obs_node && isnode;
+  double ox[NOB], oy[NOB], ix2[NOB], iy2[NOB];
+#pragma unroll
+  for (int j = 0; j < NOBS; ++j) {
+    ox[j] = 0; oy[j] = 0; ix2[j] = 0; iy2[j] = 0;
+    if (j < nobs && obs_node) {
+      const double* q = (a.obs_kind == MPCB_OBSIN_PREDICTED)
+                            ? a.obs + (((size_t)b * nobs + j) * (N + 1) + ostep) * 6
+                            : a.obs + ((size_t)b * nobs + j) * 6;
+      double sx = c.obs_sx_fixed > 0 ? c.obs_sx_fixed : c.ego_hl + q[4] / 2 + c.safe_disl;
+      double sy = c.obs_sy_fixed > 0 ? c.obs_sy_fixed : c.ego_hw + q[5] / 2 + c.safe_disw;
+      ox[j] = q[0]; oy[j] = q[1]; ix2[j] = 1.0 / (sx * sx); iy2[j] = 1.0 / (sy * sy);
+    }
+  }
+  auto hval = [&](int j, double px, double py) {
+    double dx = px - ox[j], dy = py - oy[j];
+    return dx * dx * ix2[j] + dy * dy * iy2[j] - 1.0;
+  };
+
+  double* zbuf = lds + L.zbuf;
+  for (int i = lane; i < nz; i += 64) zbuf[i] = a.z0 ? a.z0[(size_t)b * nz + i] : 0.0;
+  wv::sync();
+  double X[NX], U[NU], lam[NX];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) U[i] = hasu ? zbuf[NU * k + i] : 0.0;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) { X[i] = isnode ? zbuf[NU * N + NX * k + i] : 0.0; lam[i] = 0.0; }
+  wv::sync();
+
+  double os;
+  {
+    double g = 0;
+    double Un[NU], Up[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) { Un[i] = wv::shfl(U[i], k + 1); Up[i] = wv::shfl(U[i], k - 1); }
+    if (hasu) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) g = fmax(g, fabs(2 * c.Q[i] * (X[i] - xs[i])));
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        double gu = 2 * c.R[i] * U[i];
+        double up = (k == 0) ? c.u_last[i] : Up[i];
+        if (k > 0 || c.du0_cost) gu += 2 * c.DR[i] * (U[i] - up);
+        if (k + 1 < N && (k + 1 > 0 || c.du0_cost)) gu -= 2 * c.DR[i] * (Un[i] - U[i]);
+        g = fmax(g, fabs(gu));
+      }
+    }
+    g = wv::uni(wv::max(g));
+    os = wv::uni((g > c.max_gradient) ? c.max_gradient / g : 1.0);
+  }
+  if (k == 0) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) X[i] = gx0[i];
+  }
+
+  int status = MPCB_ST_MAXITER, iters = 0;
+  {
+    bool bad = false;
+    if (k == 0) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) bad = bad || (X[i] < c.x_lo[i] - 1e-8) || (X[i] > c.x_hi[i] + 1e-8);
+      if (obs_node) {
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j) if (j < nobs) bad = bad || (hval(j, X[0], X[1]) < c.obs_hmin - 1e-8);
+      }
+      bad = bad || !(X[3] > 0);                         // the tyre model divides by vx
+    }
+    if (wv::any(bad)) status = MPCB_ST_INFEASIBLE_X0;
+  }
+
+  const Bnd qU0 = mk_bnd(c.u_lo[0], c.u_hi[0], c.bound_relax), qU1 = mk_bnd(c.u_lo[1], c.u_hi[1], c.bound_relax);
+  const Bnd qY = mk_bnd(c.x_lo[1], c.x_hi[1], c.bound_relax), qVx = mk_bnd(c.x_lo[3], c.x_hi[3], c.bound_relax);
+  const Bnd qVy = mk_bnd(c.x_lo[4], c.x_hi[4], c.bound_relax);
+  const Bnd qR0 = mk_bnd(c.du_lo[0], c.du_hi[0], c.bound_relax), qR1 = mk_bnd(c.du_lo[1], c.du_hi[1], c.bound_relax);
+  const Bnd qO = mk_bnd(c.obs_hmin, 1e308, c.bound_relax);
+  const bool bu0_on = hasu && qU0.on, bu1_on = hasu && qU1.on;
+  const bool by_on = xnode && qY.on, bvx_on = xnode && qVx.on, bvy_on = xnode && qVy.on;
+  const bool r0_on = xcost && qR0.on, r1_on = xcost && qR1.on;
+  const bool ro_node = xnode && obs_node;
+  const bool ducost = hasu && (k > 0 || c.du0_cost);     // (U_k - U_{k-1})' DR (.) present in stage k     dyn.py:221-224
+
+  if (c.init_rollout) {
+    U[0] = hasu ? fmin(fmax(U[0], c.u_lo[0]), c.u_hi[0]) : 0.0;
+    U[1] = hasu ? fmin(fmax(U[1], c.u_lo[1]), c.u_hi[1]) : 0.0;
+#pragma clang loop unroll(disable)
+    for (int s = 0; s < N; ++s) {
+      double Xs[NX]; bool okx = X[3] > 1e-3;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Xs[i] = X[i];
+      if (!okx) Xs[3] = 1e-3;
+      DynEval e; dyn_eval(c, Xs, U, e);
+      double F[NX]; dyn_F(c, Xs, U, e, F);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { const double n = wv::bcast(F[i], s); if (k == s + 1) X[i] = n; }
+    }
+  }
+
+  Item iU0{1, 1, 0, 0}, iU1{1, 1, 0, 0}, iY{1, 1, 0, 0}, iVx{1, 1, 0, 0}, iVy{1, 1, 0, 0}, iR0{1, 1, 0, 0}, iR1{1, 1, 0, 0};
+  if (bu0_on) U[0] = push_in(qU0, U[0], c.bound_push, c.bound_frac);
+  if (bu1_on) U[1] = push_in(qU1, U[1], c.bound_push, c.bound_frac);
+  if (by_on) X[1] = push_in(qY, X[1], c.bound_push, c.bound_frac);
+  if (bvx_on) X[3] = push_in(qVx, X[3], c.bound_push, c.bound_frac);
+  if (bvy_on) X[4] = push_in(qVy, X[4], c.bound_push, c.bound_frac);
+  double Up0 = wv::shfl(U[0], k - 1), Up1 = wv::shfl(U[1], k - 1);
+  double sR0 = 0, sR1 = 0, rR0 = 0, rR1 = 0;
+  if (r0_on) sR0 = push_in(qR0, U[0] - Up0, c.bound_push, c.bound_frac);
+  if (r1_on) sR1 = push_in(qR1, U[1] - Up1, c.bound_push, c.bound_frac);
+  double sO[NOB], vO[NOB], iO[NOB], rO[NOB], gO0[NOB], gO1[NOB];
+  bool ro_on[NOB];
+#pragma unroll
+  for (int j = 0; j < NOBS; ++j) {
+    ro_on[j] = ro_node && j < nobs;
+    sO[j] = ro_on[j] ? push_in(qO, hval(j, X[0], X[1]), c.bound_push, c.bound_frac) : 1.0 + qO.L;
+    vO[j] = 1.0; rO[j] = 0; gO0[j] = 0; gO1[j] = 0; iO[j] = 0;
+  }
+  auto recips = [&]() {
+    if (bu0_on) item_recip(qU0, U[0], iU0);
+    if (bu1_on) item_recip(qU1, U[1], iU1);
+    if (by_on) item_recip(qY, X[1], iY);
+    if (bvx_on) item_recip(qVx, X[3], iVx);
+    if (bvy_on) item_recip(qVy, X[4], iVy);
+    if (r0_on) item_recip(qR0, sR0, iR0);
+    if (r1_on) item_recip(qR1, sR1, iR1);
+#pragma unroll
+    for (int j = 0; j < NOBS; ++j) if (ro_on[j]) iO[j] = wv::rcp(sO[j] - qO.L);
+  };
+
+  double mu = c.mu_init, tau = fmax(TAU_MIN, 1.0 - mu);
+  double dfc[NX] = {0, 0, 0, 0, 0, 0};
+  double theta = 0, fval = 0, logsum = 0;
+  DynEval ev;
+
+  auto eval_lane = [&](const double* Xa, const double* Ua, double sR0a, double sR1a, const double* sOa, const DynEval& e,
+                       double* dfa, double& rR0a, double& rR1a, double* rOa, double& up0, double& up1, double& th, double& fl, double& prod) {
+    bool ok = true;
+    double Ft[NX]; dyn_F(c, Xa, Ua, e, Ft);
+    th = 0; fl = 0; prod = 1.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { const double xn = wv::shfl(Xa[i], k + 1); dfa[i] = hasu ? Ft[i] - xn : 0.0; th += fabs(dfa[i]); }
+    up0 = wv::shfl(Ua[0], k - 1); up1 = wv::shfl(Ua[1], k - 1);
+    auto bar = [&](const Bnd& q, double s) {
+      if (q.hasL) { const double d = s - q.L; ok = ok && (d > 0); prod *= d; }
+      if (q.hasU) { const double d = q.U - s; ok = ok && (d > 0); prod *= d; }
+    };
+    if (bu0_on) bar(qU0, Ua[0]);
+    if (bu1_on) bar(qU1, Ua[1]);
+    if (by_on) bar(qY, Xa[1]);
+    if (bvx_on) bar(qVx, Xa[3]);
+    if (bvy_on) bar(qVy, Xa[4]);
+    rR0a = 0; rR1a = 0;
+    if (r0_on) { bar(qR0, sR0a); rR0a = (Ua[0] - up0) - sR0a; th += fabs(rR0a); }
+    if (r1_on) { bar(qR1, sR1a); rR1a = (Ua[1] - up1) - sR1a; th += fabs(rR1a); }
+#pragma unroll
+    for (int j = 0; j < NOBS; ++j) { rOa[j] = 0; if (ro_on[j]) { bar(qO, sOa[j]); rOa[j] = hval(j, Xa[0], Xa[1]) - sOa[j]; th += fabs(rOa[j]); } }
+    if (isnode && !(Xa[3] > 0)) ok = false;              // vx must stay positive where the model is evaluated
+    if (hasu) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) { const double d = Xa[i] - xs[i]; fl += c.Q[i] * d * d; }
+      fl += c.R[0] * Ua[0] * Ua[0] + c.R[1] * Ua[1] * Ua[1];
+      if (ducost) {
+        const double d0 = Ua[0] - (k ? up0 : c.u_last[0]), d1 = Ua[1] - (k ? up1 : c.u_last[1]);
+        fl += c.DR[0] * d0 * d0 + c.DR[1] * d1 * d1;
+      }
+    }
+    return ok;
+  };
+
+  double n_lam, n_v;
+  {
+    double cnt = 0;
+    auto two = [&](const Bnd& q) { return (q.hasL ? 1.0 : 0.0) + (q.hasU ? 1.0 : 0.0); };
+    if (bu0_on) cnt += two(qU0);
+    if (bu1_on) cnt += two(qU1);
+    if (by_on) cnt += two(qY);
+    if (bvx_on) cnt += two(qVx);
+    if (bvy_on) cnt += two(qVy);
+    if (r0_on) cnt += two(qR0);
+    if (r1_on) cnt += two(qR1);
+#pragma unroll
+    for (int j = 0; j < NOBS; ++j) if (ro_on[j]) cnt += 1.0;
+    n_v = wv::uni(wv::sum(cnt));
+    n_lam = (double)(NX * N);
+  }
+
+  // ----- Riccati lane constants: two entries (i,j) of the 10x10 stage block per lane ---------------------------------
+  auto slotAB = [&](int r, int col) -> int {
+    if (r < NX) {
+      if (col < NX) {
+        if (r == 0) return col == 0 ? DE_ONE : col == 2 ? DE_A02 : col == 3 ? DE_A03 : col == 4 ? DE_A04 : DE_ZERO;
+        if (r == 1) return col == 1 ? DE_ONE : col == 2 ? DE_A12 : col == 3 ? DE_A13 : col == 4 ? DE_A14 : DE_ZERO;
+        if (r == 2) return col == 2 ? DE_ONE : col == 5 ? DE_T : DE_ZERO;
+        if (r == 3) return col == 3 ? DE_ONE : col == 4 ? DE_A34 : col == 5 ? DE_A35 : DE_ZERO;
+        if (r == 4) return col == 3 ? DE_A43 : col == 4 ? DE_A44 : col == 5 ? DE_A45 : DE_ZERO;
+        return col == 3 ? DE_A53 : col == 4 ? DE_A54 : col == 5 ? DE_A55 : DE_ZERO;
+      }
+      if (col == 8) return r == 4 ? DE_B4 : r == 5 ? DE_B5 : DE_ZERO;
+      if (col == 9) return r == 3 ? DE_T : DE_ZERO;
+      return DE_ZERO;
+    }
+    return (col == r + 2) ? DE_ONE : DE_ZERO;
+  };
+  auto slotH = [&](int r, int col) -> int {
+    const int lo = r < col ? r : col, hi = r < col ? col : r;
+    const int key = lo * 10 + hi;
+    switch (key) {
+      case 0: return DE_H00; case 1: return DE_H01; case 11: return DE_H11;
+      case 22: return DE_H22; case 23: return DE_H23; case 24: return DE_H24;
+      case 33: return DE_H33; case 34: return DE_H34; case 35: return DE_H35;
+      case 44: return DE_H44; case 45: return DE_H45; case 55: return DE_H55;
+      case 38: return DE_H38; case 48: return DE_H48; case 58: return DE_H58;
+      case 88: return DE_H88; case 99: return DE_H99; case 66: return DE_H66; case 77: return DE_H77;
+      case 68: return DE_H68; case 79: return DE_H79;
+      default: return DE_ZERO;
+    }
+  };
+  int ei[NSLOT], ej[NSLOT], sHij[NSLOT], sGi[NSLOT], sABj[NSLOT][NA], sABi[NSLOT][NA];
+  bool ev_[NSLOT];
+#pragma unroll
+  for (int t = 0; t < NSLOT; ++t) {
+    const int e = lane + 64 * t;
+    ev_[t] = e < NW * NW;
+    ei[t] = ev_[t] ? e / NW : 0; ej[t] = ev_[t] ? e % NW : 0;
+    sHij[t] = slotH(ei[t], ej[t]) * ld; sGi[t] = (DE_G0 + ei[t]) * ld;
+#pragma unroll
+    for (int r = 0; r < NA; ++r) { sABj[t][r] = slotAB(r, ej[t]) * ld; sABi[t][r] = slotAB(r, ei[t]) * ld; }
+  }
+  if (isnode) { ent[DE_ZERO * ld + k] = 0.0; ent[DE_ONE * ld + k] = 1.0; ent[DE_T * ld + k] = T; }
+
+  double* Pst = lds + L.Pst; double* pst = lds + L.pst; double* Kst = lds + L.Kst; double* kffs = lds + L.kff;
+  double* Wl = lds + L.W; double* ql = lds + L.q; double* Ml = lds + L.M; double* ml = lds + L.m; double* filt = lds + L.filt;
+  int nfilt = 0;
+  double theta_max = 0, theta_min = 0, dw_last = 0.0;
+  const double mu_floor = c.tol / (K_EPS + 1.0);
+  double err0 = 0, e_dual = 0, e_prim = 0;
+
+  if (status != MPCB_ST_INFEASIBLE_X0) {
+    {
+      dyn_eval(c, X, U, ev);
+      double th, fl, prod;
+      eval_lane(X, U, sR0, sR1, sO, ev, dfc, rR0, rR1, rO, Up0, Up1, th, fl, prod);
+      double sv[3] = {th, fl, log(prod)};
+      wv::reduce<3, 0>(sv, nullptr);
+      theta = wv::uni(sv[0]); fval = wv::uni(sv[1]); logsum = wv::uni(sv[2]);
+      recips();
+#pragma unroll
+      for (int j = 0; j < NOBS; ++j) if (ro_on[j]) { gO0[j] = 2 * (X[0] - ox[j]) * ix2[j]; gO1[j] = 2 * (X[1] - oy[j]) * iy2[j]; }
+    }
+    theta_max = wv::uni(1e4 * fmax(1.0, theta)); theta_min = wv::uni(1e-4 * fmax(1.0, theta));
+
+#pragma clang loop unroll(disable)
+    for (iters = 0;; ++iters) {
+      DynJac J; dyn_jac(c, X, ev, J);
+      double ln[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) ln[i] = wv::shfl(lam[i], k + 1);
+      {
+        double rX[NX] = {0, 0, 0, 0, 0, 0}, rU[NU] = {0, 0};
+        const double Un0 = wv::shfl(U[0], k + 1), Un1 = wv::shfl(U[1], k + 1);
+        const double yR0 = r0_on ? item_y(qR0, iR0) : 0.0, yR1 = r1_on ? item_y(qR1, iR1) : 0.0;
+        const double yR0n = wv::shfl(yR0, k + 1), yR1n = wv::shfl(yR1, k + 1);
+        double sum_lam = 0, sum_v = 0, svmax = 0, svmin = 1e300, prim = 0;
+        if (xnode) {
+          if (k < N) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) rX[i] += os * 2 * c.Q[i] * (X[i] - xs[i]);
+          }
+#pragma unroll
+          for (int i = 0; i < NX; ++i) { rX[i] -= lam[i]; sum_lam += fabs(lam[i]); }
+          if (k < N) {   // A^T lam_{k+1}
+            rX[0] += ln[0]; rX[1] += ln[1];
+            rX[2] += J.a02 * ln[0] + J.a12 * ln[1] + ln[2];
+            rX[3] += J.a03 * ln[0] + J.a13 * ln[1] + ln[3] + J.a43 * ln[4] + J.a53 * ln[5];
+            rX[4] += J.a04 * ln[0] + J.a14 * ln[1] + J.a34 * ln[3] + J.a44 * ln[4] + J.a54 * ln[5];
+            rX[5] += T * ln[2] + J.a35 * ln[3] + J.a45 * ln[4] + J.a55 * ln[5];
+          }
+        }
+        if (hasu) {
+          rU[0] += os * 2 * c.R[0] * U[0]; rU[1] += os * 2 * c.R[1] * U[1];
+          if (ducost) {
+            rU[0] += os * 2 * c.DR[0] * (U[0] - (k ? Up0 : c.u_last[0]));
+            rU[1] += os * 2 * c.DR[1] * (U[1] - (k ? Up1 : c.u_last[1]));
+          }
+          if (k + 1 < N) { rU[0] -= os * 2 * c.DR[0] * (Un0 - U[0]); rU[1] -= os * 2 * c.DR[1] * (Un1 - U[1]); }
+          rU[0] += J.b4 * ln[4] + J.b5 * ln[5]; rU[1] += T * ln[3];
+          if (k + 1 < N) { rU[0] += yR0n; rU[1] += yR1n; }
+        }
+        auto item = [&](const Bnd& q, double s, const Item& it) {
+          if (q.hasL) { const double p = (s - q.L) * it.vL; svmax = fmax(svmax, p); svmin = fmin(svmin, p); sum_v += it.vL; }
+          if (q.hasU) { const double p = (q.U - s) * it.vU; svmax = fmax(svmax, p); svmin = fmin(svmin, p); sum_v += it.vU; }
+        };
+        if (bu0_on) { rU[0] -= item_y(qU0, iU0); item(qU0, U[0], iU0); }
+        if (bu1_on) { rU[1] -= item_y(qU1, iU1); item(qU1, U[1], iU1); }
+        if (by_on) { rX[1] -= item_y(qY, iY); item(qY, X[1], iY); }
+        if (bvx_on) { rX[3] -= item_y(qVx, iVx); item(qVx, X[3], iVx); }
+        if (bvy_on) { rX[4] -= item_y(qVy, iVy); item(qVy, X[4], iVy); }
+        if (r0_on) { rU[0] -= yR0; item(qR0, sR0, iR0); prim = fmax(prim, fabs(rR0)); }
+        if (r1_on) { rU[1] -= yR1; item(qR1, sR1, iR1); prim = fmax(prim, fabs(rR1)); }
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
+          rX[0] -= vO[j] * gO0[j]; rX[1] -= vO[j] * gO1[j];
+          const double p = (sO[j] - qO.L) * vO[j]; svmax = fmax(svmax, p); svmin = fmin(svmin, p); sum_v += vO[j];
+          prim = fmax(prim, fabs(rO[j]));
+        }
+        double dual = 0;
+        if (xnode) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) dual = fmax(dual, fabs(rX[i]));
+        }
+        if (hasu) {
+          dual = fmax(dual, fmax(fabs(rU[0]), fabs(rU[1])));
+#pragma unroll
+          for (int i = 0; i < NX; ++i) prim = fmax(prim, fabs(dfc[i]));
+        }
+        double ss[2] = {sum_lam, sum_v}, mm[4] = {dual, prim, svmax, -svmin};
+        wv::reduce<2, 4>(ss, mm);
+        e_dual = wv::uni(mm[0]); e_prim = wv::uni(mm[1]);
+        const double sv_hi = wv::uni(mm[2]), sv_lo = -wv::uni(mm[3]);
+        const double e_sd = fmax(S_MAX, (wv::uni(ss[0]) + wv::uni(ss[1])) / fmax(1.0, n_lam + n_v)) / S_MAX;
+        const double e_sc = fmax(S_MAX, wv::uni(ss[1]) / fmax(1.0, n_v)) / S_MAX;
+        const double base = fmax(e_dual / e_sd, e_prim);
+        err0 = fmax(base, (n_v > 0 ? sv_hi : 0.0) / e_sc);
+        if (a.trace && b == a.trace_instance && lane == 0) {
+          double* t = a.trace + (size_t)iters * 8;
+          t[0] = mu; t[1] = err0; t[2] = theta; t[3] = fval;
+        }
+        if (err0 <= c.tol) { status = MPCB_ST_SOLVED; break; }
+        if (iters >= c.max_iter) { status = MPCB_ST_MAXITER; break; }
+        for (;;) {
+          const double comp = (n_v > 0) ? fmax(fabs(sv_hi - mu), fabs(sv_lo - mu)) : 0.0;
+          const double em = fmax(base, comp / e_sc);
+          if (em <= K_EPS * mu && mu > mu_floor) {
+            mu = wv::uni(fmax(mu_floor, fmin(K_MU * mu, mu * sqrt(mu))));
+            tau = wv::uni(fmax(TAU_MIN, 1.0 - mu));
+            nfilt = 0;
+          } else break;
+        }
+      }
+
+      // ----- condensed stage QP entries of node k -----------------------------------------------------------------------
+      double hd[NW] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};    // diagonal of the stage Hessian (dw is added to X and U parts)
+      {
+        double g[NW] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        double h01 = 0, h68 = 0, h79 = 0;
+        DynHess Hh = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (xcost) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) { hd[i] += os * 2 * c.Q[i]; g[i] += os * 2 * c.Q[i] * (X[i] - xs[i]); }
+        }
+        if (hasu) {
+          hd[8] += os * 2 * c.R[0]; hd[9] += os * 2 * c.R[1];
+          g[8] += os * 2 * c.R[0] * U[0]; g[9] += os * 2 * c.R[1] * U[1];
+          if (ducost) {
+            const double w0 = os * 2 * c.DR[0], w1 = os * 2 * c.DR[1];
+            const double d0 = U[0] - (k ? Up0 : c.u_last[0]), d1 = U[1] - (k ? Up1 : c.u_last[1]);
+            hd[8] += w0; hd[6] += w0; h68 -= w0; hd[9] += w1; hd[7] += w1; h79 -= w1;
+            g[8] += w0 * d0; g[6] -= w0 * d0; g[9] += w1 * d1; g[7] -= w1 * d1;
+          }
+          dyn_hess(c, X, ev, ln, Hh);
+          hd[2] += Hh.h22; hd[3] += Hh.h33; hd[4] += Hh.h44; hd[5] += Hh.h55; hd[8] += Hh.h88;
+        }
+        double sig, gb;
+        if (bu0_on) { item_sig_gb(iU0, 0.0, mu, sig, gb); hd[8] += sig; g[8] -= gb; }
+        if (bu1_on) { item_sig_gb(iU1, 0.0, mu, sig, gb); hd[9] += sig; g[9] -= gb; }
+        if (by_on) { item_sig_gb(iY, 0.0, mu, sig, gb); hd[1] += sig; g[1] -= gb; }
+        if (bvx_on) { item_sig_gb(iVx, 0.0, mu, sig, gb); hd[3] += sig; g[3] -= gb; }
+        if (bvy_on) { item_sig_gb(iVy, 0.0, mu, sig, gb); hd[4] += sig; g[4] -= gb; }
+        if (r0_on) { item_sig_gb(iR0, rR0, mu, sig, gb); hd[8] += sig; hd[6] += sig; h68 -= sig; g[8] -= gb; g[6] += gb; }
+        if (r1_on) { item_sig_gb(iR1, rR1, mu, sig, gb); hd[9] += sig; hd[7] += sig; h79 -= sig; g[9] -= gb; g[7] += gb; }
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
+          sig = vO[j] * iO[j]; gb = mu * iO[j] - sig * rO[j];
+          hd[0] += sig * gO0[j] * gO0[j] - vO[j] * 2 * ix2[j];
+          h01 += sig * gO0[j] * gO1[j];
+          hd[1] += sig * gO1[j] * gO1[j] - vO[j] * 2 * iy2[j];
+          g[0] -= gb * gO0[j]; g[1] -= gb * gO1[j];
+        }
+        if (isnode) {
+          const double z = hasu ? 1.0 : 0.0;
+          ent[DE_A02 * ld + k] = z * J.a02; ent[DE_A03 * ld + k] = z * J.a03; ent[DE_A04 * ld + k] = z * J.a04;
+          ent[DE_A12 * ld + k] = z * J.a12; ent[DE_A13 * ld + k] = z * J.a13; ent[DE_A14 * ld + k] = z * J.a14;
+          ent[DE_A34 * ld + k] = z * J.a34; ent[DE_A35 * ld + k] = z * J.a35;
+          ent[DE_A43 * ld + k] = z * J.a43; ent[DE_A44 * ld + k] = z * J.a44; ent[DE_A45 * ld + k] = z * J.a45;
+          ent[DE_A53 * ld + k] = z * J.a53; ent[DE_A54 * ld + k] = z * J.a54; ent[DE_A55 * ld + k] = z * J.a55;
+          ent[DE_B4 * ld + k] = z * J.b4; ent[DE_B5 * ld + k] = z * J.b5;
+#pragma unroll
+          for (int i = 0; i < NX; ++i) ent[(DE_D0 + i) * ld + k] = dfc[i];
+#pragma unroll
+          for (int i = 0; i < NW; ++i) ent[(DE_G0 + i) * ld + k] = g[i];
+          ent[DE_H01 * ld + k] = h01; ent[DE_H23 * ld + k] = Hh.h23; ent[DE_H24 * ld + k] = Hh.h24;
+          ent[DE_H34 * ld + k] = Hh.h34; ent[DE_H35 * ld + k] = Hh.h35; ent[DE_H45 * ld + k] = Hh.h45;
+          ent[DE_H38 * ld + k] = Hh.h38; ent[DE_H48 * ld + k] = Hh.h48; ent[DE_H58 * ld + k] = Hh.h58;
+          ent[DE_H66 * ld + k] = hd[6]; ent[DE_H77 * ld + k] = hd[7]; ent[DE_H68 * ld + k] = h68; ent[DE_H79 * ld + k] = h79;
+        }
+      }
+
+      // ----- factorisation with inertia correction ---------------------------------------------------------------------
+      double dw = 0.0; bool first_try = true, fact_ok = false;
+#pragma clang loop unroll(disable)
+      for (int tries = 0; tries < 60; ++tries) {
+        if (isnode) {
+          const double dx_ = xnode ? dw : 0.0, du_ = hasu ? dw : 0.0;
+          ent[DE_H00 * ld + k] = hd[0] + dx_; ent[DE_H11 * ld + k] = hd[1] + dx_; ent[DE_H22 * ld + k] = hd[2] + dx_;
+          ent[DE_H33 * ld + k] = hd[3] + dx_; ent[DE_H44 * ld + k] = hd[4] + dx_; ent[DE_H55 * ld + k] = hd[5] + dx_;
+          ent[DE_H88 * ld + k] = hd[8] + du_; ent[DE_H99 * ld + k] = hd[9] + du_;
+        }
+        wv::sync();
+#pragma unroll
+        for (int t = 0; t < NSLOT; ++t) if (ev_[t] && ei[t] < NA && ej[t] < NA) {
+          Pst[N * NA * NA + ei[t] * NA + ej[t]] = ent[sHij[t] + N];
+          if (ej[t] == 0) pst[N * NA + ei[t]] = ent[sGi[t] + N];
+        }
+        wv::sync();
+        bool pd = true;
+#pragma clang loop unroll(disable)
+        for (int s = N - 1; s >= 0; --s) {
+          const double* Pn = Pst + (s + 1) * NA * NA;
+#pragma unroll
+          for (int t = 0; t < NSLOT; ++t) if (ev_[t] && ei[t] < NA) {
+            const double* Pr = Pn + ei[t] * NA;
+            double w = 0;
+#pragma unroll
+            for (int r = 0; r < NA; ++r) w += Pr[r] * ent[sABj[t][r] + s];
+            Wl[ej[t] * NA + ei[t]] = w;
+            if (ej[t] == 0) {
+              double qv = pst[(s + 1) * NA + ei[t]];
+#pragma unroll
+              for (int r = 0; r < NX; ++r) qv += Pr[r] * ent[(DE_D0 + r) * ld + s];
+              ql[ei[t]] = qv;
+            }
+          }
+          wv::sync();
+#pragma unroll
+          for (int t = 0; t < NSLOT; ++t) if (ev_[t]) {
+            double Mij = ent[sHij[t] + s], mi = ent[sGi[t] + s];
+#pragma unroll
+            for (int r = 0; r < NA; ++r) { const double ab = ent[sABi[t][r] + s]; Mij += ab * Wl[ej[t] * NA + r]; mi += ab * ql[r]; }
+            Ml[ei[t] * NW + ej[t]] = Mij;
+            if (ej[t] == 0) ml[ei[t]] = mi;
+          }
+          wv::sync();
+          const double m11 = Ml[NA * NW + NA], m12 = 0.5 * (Ml[NA * NW + NA + 1] + Ml[(NA + 1) * NW + NA]), m22 = Ml[(NA + 1) * NW + NA + 1];
+          const double det = m11 * m22 - m12 * m12;
+          if (!(m11 > 0) || !(det > 1e-14 * m11 * m22) || !isfinite(det)) { pd = false; break; }
+          const double idet = 1.0 / det;
+          const double i11 = m22 * idet, i12 = -m12 * idet, i22 = m11 * idet;
+          const double mu8 = ml[NA], mu9 = ml[NA + 1];
+          const double kf0 = -(i11 * mu8 + i12 * mu9), kf1 = -(i12 * mu8 + i22 * mu9);
+#pragma unroll
+          for (int t = 0; t < NSLOT; ++t) if (ev_[t] && ei[t] < NA && ej[t] < NA) {
+            const double M8j = Ml[NA * NW + ej[t]], M9j = Ml[(NA + 1) * NW + ej[t]];
+            const double Mi8 = Ml[ei[t] * NW + NA], Mi9 = Ml[ei[t] * NW + NA + 1];
+            const double K0j = -(i11 * M8j + i12 * M9j), K1j = -(i12 * M8j + i22 * M9j);
+            Pst[s * NA * NA + ei[t] * NA + ej[t]] = Ml[ei[t] * NW + ej[t]] + Mi8 * K0j + Mi9 * K1j;
+            if (ei[t] == 0) { Kst[s * 2 * NA + ej[t]] = K0j; Kst[s * 2 * NA + NA + ej[t]] = K1j; }
+            if (ej[t] == 0) pst[s * NA + ei[t]] = ml[ei[t]] + Mi8 * kf0 + Mi9 * kf1;
+          }
+          if (lane == 0) { kffs[s * 2] = kf0; kffs[s * 2 + 1] = kf1; }
+          wv::sync();
+        }
+        if (pd) { fact_ok = true; if (dw > 0) dw_last = dw; break; }
+        if (first_try) { dw = (dw_last == 0.0) ? DW_FIRST : fmax(DW_MIN, KW_MINUS * dw_last); first_try = false; }
+        else dw *= (dw_last == 0.0) ? KW_PLUS_FIRST : KW_PLUS;
+        if (dw > DW_MAX) break;
+      }
+      if (!fact_ok) { status = MPCB_ST_NUMERIC; break; }
+
+      // ----- forward roll-out of the step ------------------------------------------------------------------------------
+      double dX[NX] = {0, 0, 0, 0, 0, 0}, dU[NU] = {0, 0};
+      {
+        double dx[NA] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma clang loop unroll(disable)
+        for (int s = 0; s < N; ++s) {
+          const double* Ks = Kst + s * 2 * NA;
+          double du0 = kffs[s * 2], du1 = kffs[s * 2 + 1];
+#pragma unroll
+          for (int r = 0; r < NA; ++r) { du0 += Ks[r] * dx[r]; du1 += Ks[NA + r] * dx[r]; }
+          auto E = [&](int e) { return ent[e * ld + s]; };
+          const double n0 = dx[0] + E(DE_A02) * dx[2] + E(DE_A03) * dx[3] + E(DE_A04) * dx[4] + E(DE_D0);
+          const double n1 = dx[1] + E(DE_A12) * dx[2] + E(DE_A13) * dx[3] + E(DE_A14) * dx[4] + E(DE_D1);
+          const double n2 = dx[2] + T * dx[5] + E(DE_D2);
+          const double n3 = dx[3] + E(DE_A34) * dx[4] + E(DE_A35) * dx[5] + T * du1 + E(DE_D3);
+          const double n4 = E(DE_A43) * dx[3] + E(DE_A44) * dx[4] + E(DE_A45) * dx[5] + E(DE_B4) * du0 + E(DE_D4);
+          const double n5 = E(DE_A53) * dx[3] + E(DE_A54) * dx[4] + E(DE_A55) * dx[5] + E(DE_B5) * du0 + E(DE_D5);
+          if (k == s) { dU[0] = du0; dU[1] = du1; }
+          if (k == s + 1) { dX[0] = n0; dX[1] = n1; dX[2] = n2; dX[3] = n3; dX[4] = n4; dX[5] = n5; }
+          dx[0] = n0; dx[1] = n1; dx[2] = n2; dx[3] = n3; dx[4] = n4; dx[5] = n5; dx[6] = du0; dx[7] = du1;
+        }
+      }
+      const double dUp0 = wv::shfl(dU[0], k - 1), dUp1 = wv::shfl(dU[1], k - 1);
+      double lamF[NX] = {0, 0, 0, 0, 0, 0};
+      if (xnode) {
+        const double* Pk = Pst + k * NA * NA;
+        const double dxa[NA] = {dX[0], dX[1], dX[2], dX[3], dX[4], dX[5], dUp0, dUp1};
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          double s = pst[k * NA + i];
+#pragma unroll
+          for (int r = 0; r < NA; ++r) s += Pk[i * NA + r] * dxa[r];
+          lamF[i] = s;
+        }
+      }
+      const double dsR0 = r0_on ? (dU[0] - dUp0) + rR0 : 0.0, dsR1 = r1_on ? (dU[1] - dUp1) + rR1 : 0.0;
+      double dsO[NOB];
+#pragma unroll
+      for (int j = 0; j < NOBS; ++j) dsO[j] = ro_on[j] ? gO0[j] * dX[0] + gO1[j] * dX[1] + rO[j] : 0.0;
+
+      double a_pr, a_du, dphi;
+      {
+        double rpr = 0, rdu = 0, d = 0;
+        auto ftb = [&](const Bnd& q, const Item& it, double ds) {
+          double dvL, dvU; item_dv(q, it, ds, mu, dvL, dvU);
+          if (q.hasL) { rpr = fmax(rpr, -ds * it.iL); rdu = fmax(rdu, -dvL * wv::rcp(it.vL)); d -= mu * ds * it.iL; }
+          if (q.hasU) { rpr = fmax(rpr, ds * it.iU); rdu = fmax(rdu, -dvU * wv::rcp(it.vU)); d += mu * ds * it.iU; }
+        };
+        if (bu0_on) ftb(qU0, iU0, dU[0]);
+        if (bu1_on) ftb(qU1, iU1, dU[1]);
+        if (by_on) ftb(qY, iY, dX[1]);
+        if (bvx_on) ftb(qVx, iVx, dX[3]);
+        if (bvy_on) ftb(qVy, iVy, dX[4]);
+        if (r0_on) ftb(qR0, iR0, dsR0);
+        if (r1_on) ftb(qR1, iR1, dsR1);
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
+          const double dv = mu * iO[j] - vO[j] - vO[j] * iO[j] * dsO[j];
+          rpr = fmax(rpr, -dsO[j] * iO[j]); rdu = fmax(rdu, -dv * wv::rcp(vO[j])); d -= mu * dsO[j] * iO[j];
+        }
+        if (xcost) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) d += os * 2 * c.Q[i] * (X[i] - xs[i]) * dX[i];
+        }
+        if (hasu) {
+          d += os * 2 * c.R[0] * U[0] * dU[0] + os * 2 * c.R[1] * U[1] * dU[1];
+          if (ducost) {
+            d += os * 2 * c.DR[0] * (U[0] - (k ? Up0 : c.u_last[0])) * (dU[0] - (k ? dUp0 : 0.0));
+            d += os * 2 * c.DR[1] * (U[1] - (k ? Up1 : c.u_last[1])) * (dU[1] - (k ? dUp1 : 0.0));
+          }
+        }
+        double ss[1] = {d}, mm[2] = {rpr, rdu};
+        wv::reduce<1, 2>(ss, mm);
+        dphi = wv::uni(ss[0]);
+        const double r1 = wv::uni(mm[0]), r2 = wv::uni(mm[1]);
+        a_pr = wv::uni((r1 > tau) ? tau / r1 : 1.0);
+        a_du = wv::uni((r2 > tau) ? tau / r2 : 1.0);
+      }
+      const double phi0 = wv::uni(os * fval - mu * logsum), th0 = theta;
+      double a_min;
+      if (dphi < 0) {
+        a_min = fmin(G_THETA, G_PHI * th0 / (-dphi));
+        if (th0 <= theta_min) a_min = fmin(a_min, DELTA * pow(th0, S_THETA) / pow(-dphi, S_PHI));
+      } else a_min = G_THETA;
+      a_min = wv::uni(a_min * G_ALPHA);
+
+      double alpha = a_pr; bool accepted = false, armijo_type = false;
+      double Xt[NX], Ut[NU], dft[NX], sR0t, sR1t, rR0t, rR1t, sOt[NOB], rOt[NOB], upt0, upt1, tht = 0, ft = 0, lst = 0;
+      DynEval et;
+#pragma clang loop unroll(disable)
+      for (;;) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Xt[i] = X[i] + alpha * dX[i];
+        Ut[0] = U[0] + alpha * dU[0]; Ut[1] = U[1] + alpha * dU[1];
+        sR0t = sR0 + alpha * dsR0; sR1t = sR1 + alpha * dsR1;
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j) sOt[j] = sO[j] + alpha * dsO[j];
+        dyn_eval(c, Xt, Ut, et);
+        double th, fl, prod;
+        const bool okl = eval_lane(Xt, Ut, sR0t, sR1t, sOt, et, dft, rR0t, rR1t, rOt, upt0, upt1, th, fl, prod);
+        double sv[4] = {th, fl, okl ? log(prod) : 0.0, okl ? 0.0 : 1.0};
+        wv::reduce<4, 0>(sv, nullptr);
+        tht = wv::uni(sv[0]); ft = wv::uni(sv[1]); lst = wv::uni(sv[2]);
+        const double phit = os * ft - mu * lst;
+        const bool ok = (wv::uni(sv[3]) == 0.0) && isfinite(tht) && isfinite(phit);
+        if (ok && tht <= theta_max) {
+          bool fok = true;
+          for (int e = lane; e < nfilt; e += 64) if (tht >= filt[2 * e] && phit >= filt[2 * e + 1]) fok = false;
+          if (wv::all(fok)) {
+            bool sw = false;
+            if (th0 <= theta_min && dphi < 0) sw = alpha * pow(-dphi, S_PHI) > DELTA * pow(th0, S_THETA);
+            if (th0 <= theta_min && sw) {
+              if (phit <= phi0 + ETA_PHI * alpha * dphi || phit - phi0 <= 10 * 2.2e-16 * fabs(phi0)) { accepted = true; armijo_type = true; }
+            } else if (tht <= (1 - G_THETA) * th0 || phit <= phi0 - G_PHI * th0) accepted = true;
+          }
+        }
+        if (accepted) break;
+        alpha = wv::uni(alpha * 0.5);
+        if (alpha < a_min || alpha < 1e-16) break;
+      }
+      if (a.trace && b == a.trace_instance && lane == 0) {
+        double* t = a.trace + (size_t)iters * 8;
+        t[4] = a_pr; t[5] = accepted ? alpha : 0.0; t[6] = a_du; t[7] = dw;
+      }
+      if (!accepted) { status = MPCB_ST_LINESEARCH; break; }
+      if (!armijo_type) {
+        if (nfilt < FILTER_MAX) {
+          if (lane == 0) { filt[2 * nfilt] = (1 - G_THETA) * th0; filt[2 * nfilt + 1] = phi0 - G_PHI * th0; }
+          ++nfilt;
+        }
+        wv::sync();
+      }
+
+      auto upd = [&](const Bnd& q, Item& it, double ds, double snew) {
+        double dvL, dvU; item_dv(q, it, ds, mu, dvL, dvU);
+        it.vL += a_du * dvL; it.vU += a_du * dvU;
+        item_recip(q, snew, it);
+        if (q.hasL) it.vL = fmax(fmin(it.vL, K_SIGMA * mu * it.iL), mu * it.iL / K_SIGMA);
+        if (q.hasU) it.vU = fmax(fmin(it.vU, K_SIGMA * mu * it.iU), mu * it.iU / K_SIGMA);
+      };
+      if (bu0_on) upd(qU0, iU0, dU[0], Ut[0]);
+      if (bu1_on) upd(qU1, iU1, dU[1], Ut[1]);
+      if (by_on) upd(qY, iY, dX[1], Xt[1]);
+      if (bvx_on) upd(qVx, iVx, dX[3], Xt[3]);
+      if (bvy_on) upd(qVy, iVy, dX[4], Xt[4]);
+      if (r0_on) upd(qR0, iR0, dsR0, sR0t);
+      if (r1_on) upd(qR1, iR1, dsR1, sR1t);
+#pragma unroll
+      for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
+        const double dv = mu * iO[j] - vO[j] - vO[j] * iO[j] * dsO[j];
+        vO[j] += a_du * dv;
+        iO[j] = wv::rcp(sOt[j] - qO.L);
+        vO[j] = fmax(fmin(vO[j], K_SIGMA * mu * iO[j]), mu * iO[j] / K_SIGMA);
+      }
+      if (xnode) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { X[i] = Xt[i]; lam[i] += alpha * (lamF[i] - lam[i]); }
+      }
+      if (hasu) { U[0] = Ut[0]; U[1] = Ut[1]; }
+      sR0 = sR0t; sR1 = sR1t; rR0 = rR0t; rR1 = rR1t; Up0 = upt0; Up1 = upt1;
+      ev = et;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) dfc[i] = dft[i];
+#pragma unroll
+      for (int j = 0; j < NOBS; ++j) {
+        sO[j] = sOt[j]; rO[j] = rOt[j];
+        if (ro_on[j]) { gO0[j] = 2 * (X[0] - ox[j]) * ix2[j]; gO1[j] = 2 * (X[1] - oy[j]) * iy2[j]; }
+      }
+      theta = tht; fval = ft; logsum = lst;
+      if (!isfinite(theta) || !isfinite(fval)) { status = MPCB_ST_NUMERIC; break; }
+    }
+  } else {
+    double Xs[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) Xs[i] = X[i];
+    if (!(Xs[3] > 1e-3)) Xs[3] = 1e-3;
+    dyn_eval(c, Xs, U, ev);
+    double th, fl, prod;
+    eval_lane(Xs, U, sR0, sR1, sO, ev, dfc, rR0, rR1, rO, Up0, Up1, th, fl, prod);
+    fval = wv::sum(fl);
+  }
+
+  // ----- outputs -----------------------------------------------------------------------------------------------------------
+  wv::sync();
+  if (hasu) { zbuf[NU * k] = U[0]; zbuf[NU * k + 1] = U[1]; }
+  if (isnode) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) zbuf[NU * N + NX * k + i] = X[i];
+  }
+  wv::sync();
+  for (int i = lane; i < nz; i += 64) a.z[(size_t)b * nz + i] = zbuf[i];
+  if (lane == 0) {
+    if (a.obj) a.obj[b] = fval;
+    if (a.status) a.status[b] = status;
+    if (a.iters) a.iters[b] = iters;
+    if (a.kkt) { double* q = a.kkt + (size_t)b * 4; q[0] = err0; q[1] = e_prim; q[2] = e_dual / os; q[3] = mu; }
+  }
+  if (a.want_mult && a.lam_x) {
+    wv::sync();
+    for (int i = lane; i < nz; i += 64) zbuf[i] = 0.0;
+    wv::sync();
+    if (bu0_on) zbuf[NU * k] = -item_y(qU0, iU0) / os;
+    if (bu1_on) zbuf[NU * k + 1] = -item_y(qU1, iU1) / os;
+    if (by_on) zbuf[NU * N + NX * k + 1] = -item_y(qY, iY) / os;
+    if (bvx_on) zbuf[NU * N + NX * k + 3] = -item_y(qVx, iVx) / os;
+    if (bvy_on) zbuf[NU * N + NX * k + 4] = -item_y(qVy, iVy) / os;
+    wv::sync();
+    for (int i = lane; i < nz; i += 64) a.lam_x[(size_t)b * nz + i] = zbuf[i];
+  }
+  if (a.want_mult && a.lam_g) {
+    // g order: [X_0 - P](6); then per stage i: dynamics(6) and, for i > 0, the rate rows (interleaved, dyn.py:226-231)
+    // or all dynamics rows followed by the rate block; then the obstacle rows
+    double* out = a.lam_g + (size_t)b * a.ng;
+    const int nr = (qR0.on ? 1 : 0) + (qR1.on ? 1 : 0);
+    double ln[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) ln[i] = wv::shfl(lam[i], k + 1);
+    auto dyn_row = [&](int node) { return c.rate_interleaved ? NX + (node - 1) * NX + (node >= 2 ? (node - 2) * nr : 0) : NX + (node - 1) * NX; };
+    auto rate_row = [&](int node) { return c.rate_interleaved ? NX + (node + 1) * NX + (node - 1) * nr : NX + NX * N + (node - 1) * nr; };
+    const int r_obs = NX * (N + 1) + nr * (N - 1);
+    if (xnode) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) out[dyn_row(k) + i] = -lam[i] / os;
+    }
+    if (k == 0) {
+      DynJac J; dyn_jac(c, X, ev, J);
+      const double At[NX] = {ln[0], ln[1], J.a02 * ln[0] + J.a12 * ln[1] + ln[2],
+                             J.a03 * ln[0] + J.a13 * ln[1] + ln[3] + J.a43 * ln[4] + J.a53 * ln[5],
+                             J.a04 * ln[0] + J.a14 * ln[1] + J.a34 * ln[3] + J.a44 * ln[4] + J.a54 * ln[5],
+                             T * ln[2] + J.a35 * ln[3] + J.a45 * ln[4] + J.a55 * ln[5]};
+#pragma unroll
+      for (int i = 0; i < NX; ++i) out[i] = -2 * c.Q[i] * (X[i] - xs[i]) - At[i] / os;
+    }
+    if (xcost) {
+      int q = 0;
+      if (qR0.on) out[rate_row(k) + q++] = r0_on ? -item_y(qR0, iR0) / os : 0.0;
+      if (qR1.on) out[rate_row(k) + q++] = r1_on ? -item_y(qR1, iR1) / os : 0.0;
+    }
+    if (isnode) {
+      const int row = (c.obs_mode == MPCB_OBS_KEEPOUT) ? k : k - 1;
+#pragma unroll
+      for (int j = 0; j < NOBS; ++j) if (j < nobs && row >= 0 && row <= last_row) out[r_obs + row * nobs + j] = ro_on[j] ? -vO[j] / os : 0.0;
+    }
+  }
+}

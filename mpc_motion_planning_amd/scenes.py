@@ -77,3 +77,32 @@ def sample_c3(B, N=30, dt=0.1, seed=0, n_obs=3, margin=0.05):
         n += len(c)
     xs = np.tile(SHIPPED_XS, (B, 1))
     return x0, xs, obs0, predict_obstacles(obs0, dt, N)
+
+
+DYN_X0 = np.array([0.0, 0.0, 0.0, 10.0, 0.0, 0.0])            # main_cbf_dyn_c_sim.py:44
+DYN_XS = np.array([600.0, 3.5, 0.0, 15.0, 0.0, 0.0])          # main_cbf_dyn_c_sim.py:48
+DYN_OBS = np.array([[100.0, -3.5, 0.0, 0.0, 0.0, 0.0]])       # main_cbf_dyn_c_sim.py:51 (only x, y are used, dyn.py:238-239)
+
+
+def dyn_h(xy, obs, sx=4.0, sy=1.0):
+    """dyn.py:240-243: (x-ox)^2/4^2 + (y-oy)^2/1^2 - 1  (the row is sqrt(h) >= 1, i.e. h >= 1)."""
+    return (xy[..., 0] - obs[..., 0]) ** 2 / sx ** 2 + (xy[..., 1] - obs[..., 1]) ** 2 / sy ** 2 - 1.0
+
+
+def sample_c4(B, seed=0, n_obs=3):
+    """Dynamic-bicycle scenes: x0 = [x, y, phi, vx~U(8,20), 0, 0], xs = [600, 3.5, 0, 15, 0, 0],
+    n_obs static obstacles with the fixed 4 x 1 semi-axes of dyn.py:240-241, none within h < 1.5 of the start."""
+    rng = np.random.default_rng(seed)
+    x0 = np.zeros((B, 6)); obs = np.zeros((B, n_obs, 6))
+    n = 0
+    while n < B:
+        m = 2 * (B - n) + 16
+        c = np.zeros((m, 6))
+        c[:, 0] = rng.uniform(0, 30, m); c[:, 1] = rng.uniform(-0.5, 4.5, m); c[:, 2] = rng.uniform(-0.05, 0.05, m); c[:, 3] = rng.uniform(8, 20, m)
+        o = np.zeros((m, n_obs, 6))
+        o[..., 0] = rng.uniform(40, 200, (m, n_obs)); o[..., 1] = rng.choice([-3.5, 0.0, 3.5, 7.0], (m, n_obs)) + rng.uniform(-0.3, 0.3, (m, n_obs))
+        ok = np.all(dyn_h(c[:, None, :2], o) >= 1.5, axis=1)
+        c = c[ok][: B - n]; o = o[ok][: B - n]
+        x0[n:n + len(c)] = c; obs[n:n + len(c)] = o
+        n += len(c)
+    return x0, np.tile(DYN_XS, (B, 1)), obs

@@ -125,3 +125,76 @@ def certificate(nlp, z, lam_g, lam_x, act_tol=1e-6):
     cx, sx = compl(lam_x, z, nlp.lbx, nlp.ubx)
     return dict(stationarity=np.abs(stat).max(), feas_g=viol_g, feas_x=viol_x, compl=max(cg, cx), sign=max(sg, sx),
                 f=float(nlp.f(z)), lam_scale=max(1.0, np.abs(lam_g).max(), np.abs(lam_x).max()))
+
+
+class DynNlp:
+    """The dynamic-bicycle NLP (CMOM/MPC_CBF_optimize_dyn.py) for one instance, g rows and bounds ALIGNED (the
+    reference's own lbg/ubg are interleaved one stage off its g).  obs: (n_obs, >=2) static centres.
+    The obstacle row is kept in the reference's form sqrt(h) >= 1 so that this certificate also shows that the
+    solver's h >= 1 formulation reaches a KKT point of the reference's row (multipliers scale by 2 sqrt(h))."""
+
+    def __init__(self, N, T, x0, xs, obs, Q=(10, 1e5, 1e3, 1e3, 1, 1), R=(1e3, 1e3), DR=(5e3, 5e2), m=1575.0, lf=1.2, lr=1.6, Iz=2875.0,
+                 aopt_f=0.3490658503988659, aopt_r=0.19198621771937624, Cf0=-50000.0, Cr0=-50000.0, sx=4.0, sy=1.0):
+        self.N, self.T = N, T
+        self.x0 = np.asarray(x0, float).reshape(6); self.xs = np.asarray(xs, float).reshape(6)
+        self.Q, self.R, self.DR = np.asarray(Q, float), np.asarray(R, float), np.asarray(DR, float)
+        self.m, self.lf, self.lr, self.Iz, self.af, self.ar = m, lf, lr, Iz, aopt_f, aopt_r
+        self.Fyf, self.Fyr = Cf0 * aopt_f / 2, Cr0 * aopt_r / 2                       # dyn.py:55-56
+        self.obs = np.asarray(obs, float).reshape(-1, np.shape(obs)[-1])[:, :2]
+        self.n_obs, self.sx, self.sy = len(self.obs), sx, sy
+        self.nz = 2 * N + 6 * (N + 1)
+        deg = np.pi / 180
+        self.lbx = np.concatenate([np.tile([-35 * deg, -3.0], N), np.tile([-np.inf, -1.0, -np.inf, 0.0, -5.0, -np.inf], N + 1)])
+        self.ubx = np.concatenate([np.tile([35 * deg, 3.0], N), np.tile([np.inf, 5.0, np.inf, 40.0, 5.0, np.inf], N + 1)])
+        lbg, ubg = [0.0] * 6, [0.0] * 6
+        for i in range(N):
+            lbg += [0.0] * 6; ubg += [0.0] * 6
+            if i > 0:
+                lbg += [-5 * deg * T, -3.0 * T]; ubg += [5 * deg * T, 1.5 * T]
+        lbg += [1.0] * ((N + 1) * self.n_obs); ubg += [np.inf] * ((N + 1) * self.n_obs)
+        self.lbg, self.ubg = np.array(lbg), np.array(ubg)
+        self.ng = len(lbg)
+
+    def split(self, z):
+        N = self.N
+        return z[:2 * N].reshape(N, 2), z[2 * N:].reshape(N + 1, 6)
+
+    def rhs(self, X, U):                                                               # dyn.py:156-170
+        phi, vx, vy, r, df, ax = X[:, 2], X[:, 3], X[:, 4], X[:, 5], U[:, 0], U[:, 1]
+        alf = df - (vy + self.lf * r) / vx
+        alr = -(vy - self.lr * r) / vx
+        Cf = self.Fyf * 2 * self.af / (self.af ** 2 + alf ** 2)
+        Cr = self.Fyr * 2 * self.ar / (self.ar ** 2 + alr ** 2)
+        Fcf, Fcr = -Cf * alf, -Cr * alr
+        return np.stack([vx * np.cos(phi) - vy * np.sin(phi), vx * np.sin(phi) + vy * np.cos(phi), r, ax + r * vy,
+                         -r * vx + 2 / self.m * (Fcf * np.cos(df) + Fcr), 2 / self.Iz * (self.lf * Fcf - self.lr * Fcr)], axis=1)
+
+    def f(self, z):                                                                    # dyn.py:212-225
+        U, X = self.split(z)
+        e = X[:-1] - self.xs
+        dU = U[1:] - U[:-1]
+        return (e * e * self.Q).sum() + (U * U * self.R).sum() + (dU * dU * self.DR).sum()
+
+    def g(self, z):                                                                    # dyn.py:215-243
+        U, X = self.split(z)
+        rows = [X[0] - self.x0]
+        nxt = X[:-1] + self.T * self.rhs(X[:-1], U)
+        for i in range(self.N):
+            rows.append(X[i + 1] - nxt[i])
+            if i > 0:
+                rows.append(U[i] - U[i - 1])
+        for k in range(self.N + 1):
+            for j in range(self.n_obs):
+                rows.append(np.sqrt((X[k, 0] - self.obs[j, 0]) ** 2 / self.sx ** 2 + (X[k, 1] - self.obs[j, 1]) ** 2 / self.sy ** 2 - 1)[None])
+        return np.concatenate([np.asarray(r).reshape(-1) for r in rows])
+
+    grad_f = KinNlp.grad_f
+    jac_g = KinNlp.jac_g
+
+    def convert_obstacle_multipliers(self, z, lam_g):
+        """The solver's row is h >= 1 with multiplier lam_h; the reference's is sqrt(h) >= 1: lam_sqrt = 2 sqrt(h) lam_h."""
+        out = np.array(lam_g, float)
+        gv = self.g(np.asarray(z, float))
+        n0 = self.ng - (self.N + 1) * self.n_obs
+        out[n0:] = out[n0:] * 2 * gv[n0:]
+        return out

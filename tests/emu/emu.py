@@ -23,9 +23,10 @@ def lib():
 def solve(cfg, x0, xs, obs=None, z0=None, trace_instance=-1):
     x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
     xs = np.ascontiguousarray(np.atleast_2d(xs), dtype=np.float64)
-    B = x0.shape[0]; N = cfg.N; nx = 4
+    B = x0.shape[0]; N = cfg.N; nx = cfg.nx()
     nz = 2 * N + nx * (N + 1)
-    ng = nx * (N + 1) + (N - 1) + cfg.n_obs * (N + 1 if cfg.obs_terminal else N)
+    nrate = sum(1 for i in range(2) if np.isfinite(cfg.du_lo[i]) or np.isfinite(cfg.du_hi[i]))
+    ng = nx * (N + 1) + nrate * (N - 1) + cfg.n_obs * (N + 1 if cfg.obs_terminal else N)
     kind = OBSIN_STATIC
     if cfg.n_obs > 0:
         obs = np.ascontiguousarray(obs, dtype=np.float64)
@@ -44,3 +45,10 @@ def solve(cfg, x0, xs, obs=None, z0=None, trace_instance=-1):
     if rc != 0:
         raise RuntimeError("mpcb_emu_solve failed with code %d" % rc)
     return dict(z=z, obj=obj, status=st, iters=it, kkt=kkt, lam_g=lam_g, lam_x=lam_x, trace=trace)
+
+
+def dyn_model(cfg, X, U, lam):
+    X = np.ascontiguousarray(X, np.float64); U = np.ascontiguousarray(U, np.float64); lam = np.ascontiguousarray(lam, np.float64)
+    F = np.zeros(6); jac = np.zeros(16); hess = np.zeros(13)
+    lib().mpcb_emu_dyn_model(C.byref(cfg), dptr(X), dptr(U), dptr(lam), dptr(F), dptr(jac), dptr(hess))
+    return F, jac, hess

@@ -6,7 +6,7 @@
 // a GPU.  It is NOT part of libmpcbatch.so, is never loaded by the mpc_motion_planning_amd package and is far
 // too slow to be a fallback (64 OS threads per instance).
 #define MPCB_WAVE_EMU 1
-#include "../../mpc_motion_planning_amd/csrc/mpcb_kernel.h"
+#include "../../mpc_motion_planning_amd/csrc/mpcb_kernel_dyn.h"
 
 #include <thread>
 #include <vector>
@@ -19,25 +19,31 @@ thread_local Emu* t_emu = nullptr;
 template <int NOBS>
 static void run_instance(const MpcbKArgs& a, int b) {
   using namespace mpcbk;
-  Layout L = layout_kin(a.cfg.N, a.nz);
-  std::vector<double> lds(L.total + 64, 0.0);
+  const bool dyn = a.cfg.model == MPCB_MODEL_DYN;
+  const int total = dyn ? layout_dyn(a.cfg.N).total : layout_kin(a.cfg.N, a.nz).total;
+  std::vector<double> lds(total + 64, 0.0);
   std::barrier<> bar(64);
   wv::Emu emu; emu.bar = &bar;
   std::vector<std::thread> th;
   for (int l = 0; l < 64; ++l)
-    th.emplace_back([&, l]() { wv::t_lane = l; wv::t_emu = &emu; mpcb_solve_kin<NOBS>(a, b, lds.data()); });
+    th.emplace_back([&, l]() {
+      wv::t_lane = l; wv::t_emu = &emu;
+      if (dyn) mpcb_solve_dyn<NOBS>(a, b, lds.data()); else mpcb_solve_kin<NOBS>(a, b, lds.data());
+    });
   for (auto& t : th) t.join();
 }
 
 extern "C" int mpcb_emu_solve(const mpcb_config* cfg, int32_t B, const double* x0, const double* xs, const double* obs,
                               int32_t obs_kind, const double* z0, double* z, double* obj, int32_t* status, int32_t* iters,
                               double* kkt, double* lam_g, double* lam_x, double* trace, int32_t trace_instance) {
-  if (!cfg || cfg->model != MPCB_MODEL_KIN) return MPCB_E_UNSUPPORTED;
+  if (!cfg) return MPCB_E_INVALID;
+  const int nx = cfg->model == MPCB_MODEL_DYN ? 6 : 4;
+  int nrate = 0;
+  for (int i = 0; i < 2; ++i) if (cfg->du_lo[i] > -1e300 || cfg->du_hi[i] < 1e300) ++nrate;
   MpcbKArgs a;
   a.cfg = *cfg; a.B = B; a.obs_kind = obs_kind; a.want_mult = (lam_g || lam_x) ? 1 : 0; a.trace_instance = trace_instance;
-  a.nz = 2 * cfg->N + 4 * (cfg->N + 1);
-  a.ng = 4 * (cfg->N + 1) + ((cfg->du_lo[0] > -1e300 || cfg->du_hi[0] < 1e300) ? cfg->N - 1 : 0) +
-         cfg->n_obs * (cfg->obs_terminal ? cfg->N + 1 : cfg->N);
+  a.nz = 2 * cfg->N + nx * (cfg->N + 1);
+  a.ng = nx * (cfg->N + 1) + nrate * (cfg->N - 1) + cfg->n_obs * (cfg->obs_terminal ? cfg->N + 1 : cfg->N);
   a.x0 = x0; a.xs = xs; a.obs = obs; a.z0 = z0; a.z = z; a.obj = obj; a.kkt = kkt; a.lam_g = lam_g; a.lam_x = lam_x;
   a.status = status; a.iters = iters; a.trace = trace;
   for (int b = 0; b < B; ++b) {
@@ -48,4 +54,19 @@ extern "C" int mpcb_emu_solve(const mpcb_config* cfg, int32_t B, const double* x
     else return MPCB_E_UNSUPPORTED;
   }
   return MPCB_OK;
+}
+
+// closed-form dyn model derivatives of the kernel source (host-compiled) for comparison with the oracle's AD
+extern "C" int mpcb_emu_dyn_model(const mpcb_config* cfg, const double* X, const double* U, const double* lam, double* F, double* jac16,
+                                  double* hess13) {
+  using namespace mpcbk;
+  DynEval e; dyn_eval(*cfg, X, U, e);
+  dyn_F(*cfg, X, U, e, F);
+  DynJac J; dyn_jac(*cfg, X, e, J);
+  const double j[16] = {J.a02, J.a03, J.a04, J.a12, J.a13, J.a14, J.a34, J.a35, J.a43, J.a44, J.a45, J.a53, J.a54, J.a55, J.b4, J.b5};
+  for (int i = 0; i < 16; ++i) jac16[i] = j[i];
+  DynHess H; dyn_hess(*cfg, X, e, lam, H);
+  const double h[13] = {H.h22, H.h23, H.h24, H.h33, H.h34, H.h35, H.h44, H.h45, H.h55, H.h38, H.h48, H.h58, H.h88};
+  for (int i = 0; i < 13; ++i) hess13[i] = h[i];
+  return 0;
 }

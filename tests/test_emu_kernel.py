@@ -52,3 +52,27 @@ def test_emulated_kernel_failure_paths():
     assert e["status"][0] == _abi.ST_INFEASIBLE_X0 and e["iters"][0] == 0
     e = emu.solve(c, [[40.0, 3.5, 0, 25]], G["S_xs"], G["S_obs"]); r = oracle.solve(c, [[40.0, 3.5, 0, 25]], G["S_xs"], G["S_obs"])
     assert e["status"][0] == r["status"][0] != 0 and np.all(np.isfinite(e["z"]))
+
+
+def test_emulated_dyn_kernel_and_closed_form_derivatives():
+    """6-state dynamic bicycle: the kernel's hand-written tyre-model Jacobian / Hessian against the oracle's
+    forward-mode AD, and one small solve (N = 10, two entries per lane in the 10x10 Riccati block)."""
+    cfg = oracle.default_config(model=_abi.MODEL_DYN, N=10, n_obs=1); cfg.init_rollout = 1; cfg.mu_init = 10.0
+    rng = np.random.default_rng(0)
+    for _ in range(25):
+        X = np.array([rng.uniform(0, 100), rng.uniform(-1, 5), rng.uniform(-0.5, 0.5), rng.uniform(3, 30), rng.uniform(-2, 2), rng.uniform(-0.5, 0.5)])
+        U = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-3, 3)]); lam = rng.normal(size=6) * 10
+        F, A, Bm, H = oracle.model_eval(cfg, X, U, lam, ad=True)
+        Fk, j, h = emu.dyn_model(cfg, X, U, lam)
+        jr = np.array([A[0, 2], A[0, 3], A[0, 4], A[1, 2], A[1, 3], A[1, 4], A[3, 4], A[3, 5], A[4, 3], A[4, 4], A[4, 5], A[5, 3], A[5, 4], A[5, 5], Bm[4, 0], Bm[5, 0]])
+        hr = np.array([H[2, 2], H[2, 3], H[2, 4], H[3, 3], H[3, 4], H[3, 5], H[4, 4], H[4, 5], H[5, 5], H[3, 6], H[4, 6], H[5, 6], H[6, 6]])
+        assert np.allclose(F, Fk, rtol=1e-13, atol=1e-12) and np.allclose(j, jr, rtol=1e-12, atol=1e-12) and np.allclose(h, hr, rtol=1e-11, atol=1e-10)
+        # entries the kernel treats as structural constants / zeros
+        mask = np.ones((6, 6), bool)
+        for (a_, b_) in [(0, 0), (1, 1), (2, 2), (3, 3), (0, 2), (0, 3), (0, 4), (1, 2), (1, 3), (1, 4), (2, 5), (3, 4), (3, 5), (4, 3), (4, 4), (4, 5), (5, 3), (5, 4), (5, 5)]:
+            mask[a_, b_] = False
+        assert np.abs(A[mask]).max() == 0.0 and A[2, 5] == pytest.approx(0.1) and Bm[3, 1] == pytest.approx(0.1) and np.abs(Bm[:3]).max() == 0.0
+    x0 = scenes.DYN_X0[None]; xs = scenes.DYN_XS[None]; obs = np.array([[[30.0, -3.0, 0, 0, 0, 0]]])
+    e = emu.solve(cfg, x0, xs, obs); r = oracle.solve(cfg, x0, xs, obs)
+    assert e["status"][0] == r["status"][0] == 0 and e["iters"][0] == r["iters"][0]
+    assert np.abs(e["z"] - r["z"]).max() <= 1e-9 and np.abs(e["lam_g"] - r["lam_g"]).max() <= 1e-6 * np.abs(r["lam_g"]).max()

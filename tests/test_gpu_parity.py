@@ -119,7 +119,8 @@ def test_edge_cases_on_device(gpu_solver_factory):
     r = bs.solve_batch([[48.0, 3.5, 0, 10], [0.0, 6.0, 0, 10], [40.0, 3.5, 0, 25]], np.tile(scenes.SHIPPED_XS, (3, 1)), np.tile(scenes.SHIPPED_OBS, (3, 1, 1)))
     assert list(r["status"][:2]) == [_abi.ST_INFEASIBLE_X0] * 2 and r["status"][2] != 0 and np.all(np.isfinite(r["z"]))
     with pytest.raises(MpcbError):
-        gpu_solver_factory(default_config(model=_abi.MODEL_DYN, N=40, n_obs=1))
+        bad = default_config(N=30, n_obs=1); bad.obs_mode = _abi.OBS_DCBF; bad.gamma = 0.8
+        gpu_solver_factory(bad)
     with pytest.raises(ValueError):
         bs.solve_batch(np.zeros((2, 3)), np.zeros((2, 4)), np.zeros((2, 1, 6)))
     # mis-aligned bounds are rejected (the defect pattern of MPC_CBF_optimize_dyn.py:112-129)
@@ -249,3 +250,52 @@ def test_driver_counterparts_run(tmp_path):
     assert h.min() >= -1e-6 and xp[-1, 0] > 30
     z = main_kin_s_sim.main()
     assert z.shape == (184, 1)
+
+
+TOL_Z_DYN = 1e-4   # north_star's bound; the dyn cost has weights of 1 on vy and r, so IPOPT's scaled tolerance ball is wider
+
+
+def test_dynamic_bicycle_on_device(gpu_solver_factory, oracle_mod):
+    """dyn model (MPC_CBF_optimize_dyn.py): golden vector, random C4-style batches vs the oracle, tight-tolerance
+    agreement, the drop-in class with g-aligned bounds."""
+    cfg = default_config(model=_abi.MODEL_DYN, N=40, n_obs=1)
+    bs = gpu_solver_factory(cfg)
+    g = bs.solve_batch(scenes.DYN_X0[None], scenes.DYN_XS[None], scenes.DYN_OBS[None], multipliers=True)
+    assert g["status"][0] == 0 and np.abs(g["z"] - G["D_z"]).max() <= 1e-6
+    assert np.abs(g["lam_g"] - G["D_lam_g"]).max() <= 1e-5 * np.abs(G["D_lam_g"]).max()
+    from oracle import kkt_check
+    nlp = kkt_check.DynNlp(40, 0.1, scenes.DYN_X0, scenes.DYN_XS, scenes.DYN_OBS)
+    c = kkt_check.certificate(nlp, g["z"][0], nlp.convert_obstacle_multipliers(g["z"][0], g["lam_g"][0]), g["lam_x"][0])
+    assert c["stationarity"] <= 1e-6 * c["lam_scale"] and c["feas_g"] <= 2e-8 and c["compl"] <= 1e-3
+    cfg3 = default_config(model=_abi.MODEL_DYN, N=40, n_obs=3)
+    g4 = gpu_solver_factory(cfg3).solve_batch(G["C4_x0"], G["C4_xs"], G["C4_obs"])
+    assert np.array_equal(g4["status"], G["C4_status"]) and np.abs(g4["z"] - G["C4_z"]).max() <= TOL_Z_DYN
+    x0, xs, obs = scenes.sample_c4(512, seed=5, n_obs=3)
+    g = gpu_solver_factory(cfg3).solve_batch(x0, xs, obs); r = oracle_mod.solve(cfg3, x0, xs, obs)
+    agree(g, r, tol=TOL_Z_DYN, min_same_status=0.99)
+    tight = default_config(model=_abi.MODEL_DYN, N=40, n_obs=3); tight.tol = 1e-11
+    g = gpu_solver_factory(tight).solve_batch(x0[:128], xs[:128], obs[:128]); r = oracle_mod.solve(tight, x0[:128], xs[:128], obs[:128])
+    both = (g["status"] == 0) & (r["status"] == 0)
+    assert both.sum() >= 100 and np.abs(g["z"][both] - r["z"][both]).max() <= 1e-7
+    # drop-in class, reference call sequence of main_cbf_dyn_c_sim.py:39,67,89-90 (shipped YAML: horizon from the package file)
+    from mpc_motion_planning_amd import MPC_CBF_optimize_dyn, shift_movement
+    m = MPC_CBF_optimize_dyn.MPC_optimize()
+    N = m.N_p
+    x0c = scenes.DYN_X0.reshape(-1, 1); xsc = scenes.DYN_XS.reshape(-1, 1)
+    lbg, ubg, lbx, ubx = m.initialize_constraints()
+    solver = m.optimize_problem(ego_state=x0c, ref_state=xsc, obstacle=np.array([100, -3.5]))
+    res = solver(x0=np.zeros((2 * N + 6 * (N + 1), 1)), p=np.concatenate((x0c, xsc)), lbg=lbg, lbx=lbx, ubg=ubg, ubx=ubx)
+    assert solver.stats()["success"]
+    z = res["x"].full(); u0 = z[:2 * N].reshape(N, 2); x_m = z[2 * N:].reshape(N + 1, 6)
+    t, x1, u1, xf = shift_movement(m.T_S, 0.0, x0c, u0, x_m, m.f)
+    assert np.asarray(x1).shape == (6, 1) and float(np.asarray(x1)[3, 0]) > 10.0
+    # the reference's own (mis-aligned) bounds order is rejected, not silently accepted (SURVEY.md F7)
+    from mpc_motion_planning_amd._lib import MpcbError
+    bad_l, bad_u = [], []
+    for i in range(N + 1):
+        bad_l += [0.0] * 6; bad_u += [0.0] * 6
+        if 0 < i < N:
+            bad_l += [lbg[18], lbg[19]]; bad_u += [ubg[18], ubg[19]]
+    bad_l += [1.0] * (N + 1); bad_u += [np.inf] * (N + 1)
+    with pytest.raises(MpcbError):
+        solver(x0=np.zeros((2 * N + 6 * (N + 1), 1)), p=np.concatenate((x0c, xsc)), lbg=bad_l, lbx=lbx, ubg=bad_u, ubx=ubx)

@@ -125,3 +125,25 @@ def test_hand_written_kinematic_derivatives_equal_ad():
         e = np.zeros(6); e[j] = 1e-6
         Fp = oracle.model_eval(cd, X + e, U, lam, ad=True)[0]; Fm = oracle.model_eval(cd, X - e, U, lam, ad=True)[0]
         assert np.allclose((Fp - Fm) / 2e-6, A[:, j], rtol=1e-6, atol=1e-7)
+
+
+def test_dynamic_bicycle_golden_and_certificate():
+    """dyn model (CMOM/MPC_CBF_optimize_dyn.py): golden vector + KKT certificate against the reference's own row forms
+    (sqrt(h) >= 1 obstacle rows, rate rows interleaved after each stage, bounds aligned with g)."""
+    cd = oracle.default_config(model=_abi.MODEL_DYN, N=40, n_obs=1); cd.init_rollout = 1; cd.mu_init = 10.0
+    r = oracle.solve(cd, scenes.DYN_X0[None], scenes.DYN_XS[None], scenes.DYN_OBS[None])
+    assert r["status"][0] == 0 and np.abs(r["z"] - G["D_z"]).max() <= 1e-9
+    nlp = kkt_check.DynNlp(40, 0.1, scenes.DYN_X0, scenes.DYN_XS, scenes.DYN_OBS)
+    assert (nlp.nz, nlp.ng) == (326, 6 * 41 + 2 * 39 + 41)
+    lg = nlp.convert_obstacle_multipliers(r["z"][0], r["lam_g"][0])
+    c = kkt_check.certificate(nlp, r["z"][0], lg, r["lam_x"][0])
+    assert c["f"] == pytest.approx(r["obj"][0], rel=1e-13)
+    assert c["stationarity"] <= 1e-6 * c["lam_scale"] and c["feas_g"] <= 2e-8 and c["feas_x"] <= 1e-7 and c["compl"] <= 1e-3 and c["sign"] == 0.0
+    c4 = oracle.default_config(model=_abi.MODEL_DYN, N=40, n_obs=3); c4.init_rollout = 1; c4.mu_init = 10.0
+    r4 = oracle.solve(c4, G["C4_x0"], G["C4_xs"], G["C4_obs"])
+    assert np.array_equal(r4["status"], G["C4_status"]) and np.abs(r4["z"] - G["C4_z"]).max() <= 1e-9
+    # IPOPT-default-like start (all zeros, vx pushed to 0.01) hits the vx -> 0 singularity of the tyre model on the first
+    # trial points (SURVEY.md "hard parts"): reported as a failure status, never a hang or a NaN in the output
+    ci = oracle.default_config(model=_abi.MODEL_DYN, N=40, n_obs=1)
+    ri = oracle.solve(ci, scenes.DYN_X0[None], scenes.DYN_XS[None], scenes.DYN_OBS[None])
+    assert ri["status"][0] != 0 or np.abs(ri["z"] - G["D_z"]).max() <= 1e-4
