@@ -185,6 +185,12 @@ int mpcb_sync(mpcb_handle* h);
  * number of launches, total and last kernel milliseconds. */
 int mpcb_timing(mpcb_handle* h, int32_t reset, int32_t* launches, double* total_ms, double* last_ms);
 
+/* Diagnostic: solve ONE instance and return the per-iteration log  trace[(max_iter+1) * 8] =
+ * {mu, scaled NLP error, theta, f, alpha_primal_max, alpha accepted, alpha_dual, delta_w} per iteration (host pointers).
+ * Used by the parity tests to compare the iteration history with the oracle's. */
+int mpcb_solve_trace(mpcb_handle* h, const double* x0, const double* xs, const double* obs, int32_t obs_kind, const double* z0,
+                     double* z, int32_t* status, int32_t* iters, double* trace);
+
 /* Model right-hand side f(x,u) on the host (the `mpc_solver.f` the drivers call for the plant step,
  * main_cbf_kin_c_sim.py:17).  Tiny, scalar, no device involved. */
 int mpcb_model_rhs(const mpcb_config* cfg, const double* x, const double* u, double* xdot);

@@ -425,6 +425,42 @@ int mpcb_solve(mpcb_handle* h, int32_t B, const double* x0, const double* xs, co
   return MPCB_OK;
 }
 
+int mpcb_solve_trace(mpcb_handle* h, const double* x0, const double* xs, const double* obs, int32_t obs_kind, const double* z0,
+                     double* z, int32_t* status, int32_t* iters, double* trace) {
+  if (!h || !x0 || !xs || !z || !trace) return fail(h, MPCB_E_INVALID, "NULL argument");
+  if (h->cfg.n_obs > 0 && !obs) return fail(h, MPCB_E_INVALID, "n_obs = %d but obs is NULL", h->cfg.n_obs);
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int nx = h->nx, nz = h->nz, N = h->cfg.N;
+  const size_t n_obs_d = (size_t)h->cfg.n_obs * 6 * (obs_kind == MPCB_OBSIN_PREDICTED ? N + 1 : 1);
+  const size_t n_tr = (size_t)(h->cfg.max_iter + 1) * 8;
+  int rc = ensure_scratch(h, (2 * nx + 2 * nz + n_obs_d + n_tr + 64) * 8 + 8192);
+  if (rc != MPCB_OK) return rc;
+  Carve cv{(char*)h->d_buf};
+  double* d_x0 = cv.take<double>(nx); double* d_xs = cv.take<double>(nx);
+  double* d_obs = n_obs_d ? cv.take<double>(n_obs_d) : nullptr;
+  double* d_z0 = z0 ? cv.take<double>(nz) : nullptr;
+  double* d_z = cv.take<double>(nz); double* d_tr = cv.take<double>(n_tr);
+  int32_t* d_st = cv.take<int32_t>(1); int32_t* d_it = cv.take<int32_t>(1);
+  hipStream_t s = h->stream;
+  HIP_TRY(h, hipMemcpyAsync(d_x0, x0, nx * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(d_xs, xs, nx * 8, hipMemcpyHostToDevice, s));
+  if (d_obs) HIP_TRY(h, hipMemcpyAsync(d_obs, obs, n_obs_d * 8, hipMemcpyHostToDevice, s));
+  if (d_z0) HIP_TRY(h, hipMemcpyAsync(d_z0, z0, nz * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemsetAsync(d_tr, 0, n_tr * 8, s));
+  MpcbKArgs a;
+  a.cfg = h->cfg; a.B = 1; a.nz = nz; a.ng = h->ng; a.obs_kind = obs_kind; a.want_mult = 0; a.trace_instance = 0; a.trace = d_tr;
+  a.x0 = d_x0; a.xs = d_xs; a.obs = d_obs; a.z0 = d_z0; a.z = d_z; a.obj = nullptr; a.kkt = nullptr; a.lam_g = nullptr; a.lam_x = nullptr;
+  a.status = d_st; a.iters = d_it;
+  rc = launch_solve(h, a);
+  if (rc != MPCB_OK) return rc;
+  HIP_TRY(h, hipMemcpyAsync(z, d_z, nz * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(trace, d_tr, n_tr * 8, hipMemcpyDeviceToHost, s));
+  if (status) HIP_TRY(h, hipMemcpyAsync(status, d_st, 4, hipMemcpyDeviceToHost, s));
+  if (iters) HIP_TRY(h, hipMemcpyAsync(iters, d_it, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  return MPCB_OK;
+}
+
 int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps, const double* x0, const double* xs, double* obs_state, int32_t obs_motion,
                      double* x_hist, double* u_hist, int32_t* status_hist, int32_t* iters_hist) {
   if (!h) return MPCB_E_INVALID;

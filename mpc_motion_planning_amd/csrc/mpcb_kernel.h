@@ -38,6 +38,19 @@ struct MpcbKArgs {
   double* trace;   // optional: [max_iter + 1][8] log of instance trace_instance (debug / parity tests)
 };
 
+// MPCB_STAMPS (diagnostic build only, never shipped): overwrite trace columns 4..7 with cycle counts of the phases of
+// an iteration (condense+KKT, Riccati, forward+ratios, line search) instead of the step lengths.
+#if defined(MPCB_STAMPS) && !defined(MPCB_WAVE_EMU)
+#define MPCB_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define MPCB_STAMP(var) unsigned long long var = 0
+#endif
+#ifndef MPCB_WAVE_EMU
+#define MPCB_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MPCB_SCHED_FENCE() ((void)0)
+#endif
+
 namespace mpcbk {
 
 constexpr int NU = 2;
@@ -425,6 +438,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
 
 #pragma clang loop unroll(disable)
     for (iters = 0;; ++iters) {
+      MPCB_STAMP(t_a);
       // ----- KKT residuals of the scaled problem at the iterate (one pass, fused reductions) ---------------------
       const double a02 = -T * X[3] * sp, a03 = T * cp, a12 = T * X[3] * cp, a13 = T * sp, a23 = T * td * il, b20 = T * X[3] * sec2 * il;
       double ln[NX];
@@ -562,6 +576,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         }
       }
 
+      MPCB_STAMP(t_b);
       // ----- factorisation with inertia correction: backward Riccati sweep, lanes = entries ----------------------
       double dw = 0.0; bool first_try = true, fact_ok = false;
 #pragma clang loop unroll(disable)
@@ -576,35 +591,53 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         if (ei < NA && ej < NA) Pst[N * NA * NA + ei * NA + ej] = ent[sHij + N];
         if (ei < NA && ej == 0) pst[N * NA + ei] = ent[sGi + N];
         wv::sync();
-        bool pd = true;
-#pragma clang loop unroll(disable)
-        for (int s = N - 1; s >= 0; --s) {
+        // Stage entries (18 table values per lane) do not depend on the recursion: they are prefetched one stage ahead
+        // into a second register set (ping-pong, no copies) so that only the P+ row and the W exchange sit on the
+        // critical path.  MPCB_SCHED_FENCE keeps the compiler from sinking the batched loads next to their uses.
+        struct StageEnt { double abj[NA], abi[NA], hij, gi, dd[NX]; };
+        auto load_ent = [&](int s, StageEnt& e) {
+#pragma unroll
+          for (int r = 0; r < NA; ++r) { e.abj[r] = ent[sABj[r] + s]; e.abi[r] = ent[sABi[r] + s]; }
+          e.hij = ent[sHij + s]; e.gi = ent[sGi + s];
+#pragma unroll
+          for (int r = 0; r < NX; ++r) e.dd[r] = ent[(E_D0 + r) * ld + s];
+        };
+        auto stage = [&](int s, const StageEnt& e, StageEnt& nxt) -> bool {
           // W = P+ [A B],  q = p+ + P+ d          (lane (i,j): row i of P+, column j of [A B])
           const double* Pn = Pst + (s + 1) * NA * NA + eiA * NA;
-          double* Wb = Wl + (s & 1) * NW * NA; double* qb = ql + (s & 1) * NW;
-          double w = 0, qv = pst[(s + 1) * NA + eiA];
+          double Pr[NA];
 #pragma unroll
-          for (int r = 0; r < NA; ++r) w += Pn[r] * ent[sABj[r] + s];
+          for (int r = 0; r < NA; ++r) Pr[r] = Pn[r];
+          double qv = pst[(s + 1) * NA + eiA];
+          MPCB_SCHED_FENCE();
+          double w = 0;
 #pragma unroll
-          for (int r = 0; r < NX; ++r) qv += Pn[r] * ent[(E_D0 + r) * ld + s];
-          if (ei < NA) { Wb[ej * NA + ei] = w; if (ej == 0) qb[ei] = qv; }
+          for (int r = 0; r < NA; ++r) w += Pr[r] * e.abj[r];
+#pragma unroll
+          for (int r = 0; r < NX; ++r) qv += Pr[r] * e.dd[r];
+          if (ei < NA) { Wl[ej * NA + ei] = w; if (ej == 0) ql[ei] = qv; }
+          load_ent(s > 0 ? s - 1 : 0, nxt);                       // prefetch for the next stage, off the critical path
           wv::sync();
-          // M = H + [A B]^T W,  m = g + [A B]^T q
-          double Mij = ent[sHij + s], mi = ent[sGi + s];
+          double Wc[NA], qc[NA];
 #pragma unroll
-          for (int r = 0; r < NA; ++r) { const double ab = ent[sABi[r] + s]; Mij += ab * Wb[ej * NA + r]; mi += ab * qb[r]; }
+          for (int r = 0; r < NA; ++r) { Wc[r] = Wl[ej * NA + r]; qc[r] = ql[r]; }
+          MPCB_SCHED_FENCE();
+          // M = H + [A B]^T W,  m = g + [A B]^T q
+          double Mij = e.hij, mi = e.gi;
+#pragma unroll
+          for (int r = 0; r < NA; ++r) { Mij += e.abi[r] * Wc[r]; mi += e.abi[r] * qc[r]; }
           // control block Muu (lanes (6,6),(6,7),(7,6),(7,7)) and m_u (lanes (6,*),(7,*)) to every lane
           const double m11 = wv::bcast(Mij, NA * 8 + NA), m12 = 0.5 * (wv::bcast(Mij, NA * 8 + NA + 1) + wv::bcast(Mij, (NA + 1) * 8 + NA));
           const double m22 = wv::bcast(Mij, (NA + 1) * 8 + NA + 1);
           const double mu6 = wv::bcast(mi, NA * 8), mu7 = wv::bcast(mi, (NA + 1) * 8);
-          const double det = m11 * m22 - m12 * m12;
-          if (!(m11 > 0) || !(det > 1e-14 * m11 * m22) || !isfinite(det)) { pd = false; break; }
-          const double idet = 1.0 / det;
-          const double i11 = m22 * idet, i12 = -m12 * idet, i22 = m11 * idet;
-          const double kf0 = -(i11 * mu6 + i12 * mu7), kf1 = -(i12 * mu6 + i22 * mu7);
-          // rows 6,7 of M at column j, and (by symmetry of the exchange pattern) at column i
+          // rows 6,7 of M at column j and at column i (M is symmetric up to rounding)
           const double M6j = wv::shfl(Mij, NA * 8 + ej), M7j = wv::shfl(Mij, (NA + 1) * 8 + ej);
           const double M6i = wv::shfl(Mij, NA * 8 + ei), M7i = wv::shfl(Mij, (NA + 1) * 8 + ei);
+          const double det = m11 * m22 - m12 * m12;
+          if (!(m11 > 0) || !(det > 1e-14 * m11 * m22) || !isfinite(det)) return false;
+          const double idet = wv::rcp(det);
+          const double i11 = m22 * idet, i12 = -m12 * idet, i22 = m11 * idet;
+          const double kf0 = -(i11 * mu6 + i12 * mu7), kf1 = -(i12 * mu6 + i22 * mu7);
           const double K0j = -(i11 * M6j + i12 * M7j), K1j = -(i12 * M6j + i22 * M7j);
           if (ei < NA && ej < NA) {
             Pst[s * NA * NA + ei * NA + ej] = Mij + M6i * K0j + M7i * K1j;
@@ -613,6 +646,19 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           }
           if (lane == 0) { kffs[s * 2] = kf0; kffs[s * 2 + 1] = kf1; }
           wv::sync();
+          return true;
+        };
+        bool pd = true;
+        {
+          StageEnt eA, eB;
+          load_ent(N - 1, eA);
+          int s = N - 1;
+#pragma clang loop unroll(disable)
+          for (; s >= 1; s -= 2) {
+            if (!stage(s, eA, eB)) { pd = false; break; }
+            if (!stage(s - 1, eB, eA)) { pd = false; break; }
+          }
+          if (pd && s == 0) pd = stage(0, eA, eB);
         }
         if (pd) { fact_ok = true; if (dw > 0) dw_last = dw; break; }
         if (first_try) { dw = (dw_last == 0.0) ? DW_FIRST : fmax(DW_MIN, KW_MINUS * dw_last); first_try = false; }
@@ -621,22 +667,42 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       }
       if (!fact_ok) { status = MPCB_ST_NUMERIC; break; }
 
+      MPCB_STAMP(t_c);
       // ----- forward roll-out of the step: every lane carries the same 6-vector, lane k latches its node ----------
       double dX[NX] = {0, 0, 0, 0}, dU[NU] = {0, 0};
       {
-        double dx0 = 0, dx1 = 0, dx2 = 0, dx3 = 0, dx4 = 0, dx5 = 0;
-#pragma unroll 2
-        for (int s = 0; s < N; ++s) {
+        // 24 table values per stage, none of them on the recursion: prefetched one stage ahead (ping-pong registers)
+        struct FwEnt { double K[2 * NA], kf0, kf1, a02, a03, a12, a13, a23, b20, d0, d1, d2, d3; };
+        auto load_fw = [&](int s, FwEnt& f) {
           const double* Ks = Kst + s * 2 * NA;
-          const double du0 = kffs[s * 2] + (Ks[0] * dx0 + Ks[1] * dx1) + (Ks[2] * dx2 + Ks[3] * dx3) + (Ks[4] * dx4 + Ks[5] * dx5);
-          const double du1 = kffs[s * 2 + 1] + (Ks[6] * dx0 + Ks[7] * dx1) + (Ks[8] * dx2 + Ks[9] * dx3) + (Ks[10] * dx4 + Ks[11] * dx5);
-          const double n0 = dx0 + ent[E_A02 * ld + s] * dx2 + ent[E_A03 * ld + s] * dx3 + ent[E_D0 * ld + s];
-          const double n1 = dx1 + ent[E_A12 * ld + s] * dx2 + ent[E_A13 * ld + s] * dx3 + ent[E_D1 * ld + s];
-          const double n2 = dx2 + ent[E_A23 * ld + s] * dx3 + ent[E_B20 * ld + s] * du0 + ent[E_D2 * ld + s];
-          const double n3 = dx3 + T * du1 + ent[E_D3 * ld + s];
+#pragma unroll
+          for (int r = 0; r < 2 * NA; ++r) f.K[r] = Ks[r];
+          f.kf0 = kffs[s * 2]; f.kf1 = kffs[s * 2 + 1];
+          f.a02 = ent[E_A02 * ld + s]; f.a03 = ent[E_A03 * ld + s]; f.a12 = ent[E_A12 * ld + s]; f.a13 = ent[E_A13 * ld + s];
+          f.a23 = ent[E_A23 * ld + s]; f.b20 = ent[E_B20 * ld + s];
+          f.d0 = ent[E_D0 * ld + s]; f.d1 = ent[E_D1 * ld + s]; f.d2 = ent[E_D2 * ld + s]; f.d3 = ent[E_D3 * ld + s];
+        };
+        double dx0 = 0, dx1 = 0, dx2 = 0, dx3 = 0, dx4 = 0, dx5 = 0;
+        auto fstage = [&](int s, const FwEnt& f, FwEnt& nxt) {
+          load_fw(s + 1 < N ? s + 1 : s, nxt);
+          MPCB_SCHED_FENCE();
+          const double du0 = f.kf0 + (f.K[0] * dx0 + f.K[1] * dx1) + (f.K[2] * dx2 + f.K[3] * dx3) + (f.K[4] * dx4 + f.K[5] * dx5);
+          const double du1 = f.kf1 + (f.K[6] * dx0 + f.K[7] * dx1) + (f.K[8] * dx2 + f.K[9] * dx3) + (f.K[10] * dx4 + f.K[11] * dx5);
+          const double n0 = dx0 + f.a02 * dx2 + f.a03 * dx3 + f.d0;
+          const double n1 = dx1 + f.a12 * dx2 + f.a13 * dx3 + f.d1;
+          const double n2 = dx2 + f.a23 * dx3 + f.b20 * du0 + f.d2;
+          const double n3 = dx3 + T * du1 + f.d3;
           if (k == s) { dU[0] = du0; dU[1] = du1; }
           if (k == s + 1) { dX[0] = n0; dX[1] = n1; dX[2] = n2; dX[3] = n3; }
           dx0 = n0; dx1 = n1; dx2 = n2; dx3 = n3; dx4 = du0; dx5 = du1;
+        };
+        {
+          FwEnt fA, fB;
+          load_fw(0, fA);
+          int s = 0;
+#pragma clang loop unroll(disable)
+          for (; s + 1 < N; s += 2) { fstage(s, fA, fB); fstage(s + 1, fB, fA); }
+          if (s < N) fstage(s, fA, fB);
         }
       }
       const double dUp0 = wv::shfl(dU[0], k - 1), dUp1 = wv::shfl(dU[1], k - 1);   // dU_{k-1}
@@ -704,6 +770,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       } else a_min = G_THETA;
       a_min = wv::uni(a_min * G_ALPHA);
 
+      MPCB_STAMP(t_d);
       // ----- filter line search: trial evaluations are lane-parallel ----------------------------------------------
       double alpha = a_pr; bool accepted = false, armijo_type = false;
       double Xt[NX], Ut[NU], dft[NX], sRt, rRt, sOt[NOB], rOt[NOB], upt0, upt1, st_, ct_, tt_, et_, tht = 0, ft = 0, lst = 0;
@@ -741,6 +808,10 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       if (a.trace && b == a.trace_instance && lane == 0) {
         double* t = a.trace + (size_t)iters * 8;
         t[4] = a_pr; t[5] = accepted ? alpha : 0.0; t[6] = a_du; t[7] = dw;
+#if defined(MPCB_STAMPS) && !defined(MPCB_WAVE_EMU)
+        MPCB_STAMP(t_e);
+        t[4] = (double)(t_b - t_a); t[5] = (double)(t_c - t_b); t[6] = (double)(t_d - t_c); t[7] = (double)(t_e - t_d);
+#endif
       }
       if (!accepted) { status = MPCB_ST_LINESEARCH; break; }
       if (!armijo_type) {

@@ -131,6 +131,17 @@ class BatchSolver:
             out["lam_g"] = lam_g; out["lam_x"] = lam_x
         return out
 
+    def solve_trace(self, x0, xs, obs=None, z0=None):
+        """One instance with its iteration log: dict(z, status, iters, trace[iters+1, 8]) with trace columns
+        mu, scaled error, theta, f, alpha_primal_max, alpha, alpha_dual, delta_w."""
+        x0 = np.ascontiguousarray(np.asarray(x0, dtype=np.float64).reshape(1, self.nx)); xs = np.ascontiguousarray(np.asarray(xs, dtype=np.float64).reshape(1, self.nx))
+        obs, kind = self._obs(obs, 1)
+        if z0 is not None:
+            z0 = np.ascontiguousarray(np.asarray(z0, dtype=np.float64).reshape(1, self.nz))
+        z = np.empty((1, self.nz)); st = np.empty(1, np.int32); it = np.empty(1, np.int32); tr = np.zeros((self.cfg.max_iter + 1, 8))
+        check(lib().mpcb_solve_trace(self._h, dptr(x0), dptr(xs), dptr(obs), kind, dptr(z0), dptr(z), iptr(st), iptr(it), dptr(tr)), self._h)
+        return dict(z=z[0], status=int(st[0]), iters=int(it[0]), trace=tr[: int(it[0]) + 1])
+
     def closed_loop(self, x0, xs, obs_state=None, steps=80, obs_motion=_abi.OBSMOVE_STATIC):
         """Receding-horizon loop on the device (main_cbf_kin_c_sim.py:87-123).  obs_motion: OBSMOVE_STATIC (obstacles fixed,
         main_cbf_kin_c_sim.py), OBSMOVE_PREDICTED (constant-velocity obstacles predicted per solve and advanced per step,

@@ -276,6 +276,10 @@ struct Solver {
 
   Solver(const mpcb_config& cfg) : c(cfg) {
     if (std::getenv("MPCO_KSIG")) o.kappa_sigma = std::atof(std::getenv("MPCO_KSIG"));
+    if (std::getenv("MPCO_KMU")) o.kappa_mu = std::atof(std::getenv("MPCO_KMU"));
+    if (std::getenv("MPCO_THMU")) o.theta_mu = std::atof(std::getenv("MPCO_THMU"));
+    if (std::getenv("MPCO_KEPS")) o.kappa_eps = std::atof(std::getenv("MPCO_KEPS"));
+    if (std::getenv("MPCO_TAUMIN")) o.tau_min = std::atof(std::getenv("MPCO_TAUMIN"));
     N = c.N; nx = nx_of(c); na = nx + NU; nw = na + NU; nobs = c.n_obs;
   }
 
