@@ -60,12 +60,41 @@ def cpu_baseline(cfg, x0, xs, obs, min_seconds=1.5):
             "note": "own FP64 C++ restatement of the NLP + IPOPT-style solver; CasADi+IPOPT baseline unavailable (casadi not installed)"}
 
 
+def closed_loop_bench(args, bs, cfg, x0, xs, obs, workload, rank, world):
+    """C5: `steps` = number of complete 80-step closed loops; value counts solved MPC steps per second."""
+    from mpc_motion_planning_amd import _abi
+    sim_steps = 80                                            # sim_time 8 s / T_S 0.1 (main_cbf_kin_c_sim.py:68,87)
+    for _ in range(max(1, args.warmup // 3)):
+        bs.closed_loop(x0[:256], xs[:256], obs[:256], steps=4, obs_motion=_abi.OBSMOVE_PREDICTED)
+    bs.timing(reset=True)
+    t0 = time.perf_counter()
+    reps = max(1, args.steps // 10)
+    for _ in range(reps):
+        r = bs.closed_loop(x0, xs, obs, steps=sim_steps, obs_motion=_abi.OBSMOVE_PREDICTED)
+    dt = time.perf_counter() - t0
+    tm = bs.timing()
+    solved = int((r["status"] == 0).sum())
+    h = scenes.ellipse_h(r["x_hist"][:, :, None, :2], r["obs_state"][:, None, :, :])   # margin versus the final obstacle positions only
+    out = {"metric": "mpc_solves_per_sec", "value": solved * reps / dt, "unit": "solves/s", "n_gpus": world, "steps": reps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * dt / reps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": workload, "scenes_per_gpu": len(x0), "sim_steps": sim_steps, "solved_steps": solved,
+                      "failed_steps": int(r["status"].size - solved), "scenes_all_steps_solved": int((r["status"] == 0).all(axis=1).sum()),
+                      "iters_mean": float(r["iters"].mean()), "host_pointer_entry": True,
+                      "kernel_ms_avg": tm["total_ms"] / max(1, tm["launches"]), "launches": tm["launches"]}}
+    if rank == 0:
+        print(json.dumps(out))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="instances per GPU per step (default: the config's BASELINE batch)")
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
+                    help="BASELINE.json config: C2 (default, the metric's config) kin+1 static obstacle B=4096; C3 kin+3 predicted "
+                         "obstacles B=32768; C4 dyn N=40 3 obstacles B=8192/GPU; C5 closed loop 80 steps (solves = scenes x steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -87,14 +116,33 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    B = args.batch
-    cfg = default_config(model=_abi.MODEL_KIN, N=30, T=0.1, n_obs=1)
+    conf = args.config
+    B = args.batch or {"C2": 4096, "C3": 32768, "C4": 8192, "C5": 4096}[conf]
+    obs_kind = _abi.OBSIN_STATIC
+    if conf == "C2":
+        cfg = default_config(model=_abi.MODEL_KIN, N=30, T=0.1, n_obs=1)
+        x0, xs, obs = scenes.sample_c2(B, seed=1000 + rank)
+        workload = "C2: kinematic bicycle + 1 static CBF/keep-out obstacle row set (MPC_CBF_optimize_kin), N=30, T=0.1, batch %d random x0 per GPU, cold start z0=0" % B
+    elif conf == "C3":
+        cfg = default_config(model=_abi.MODEL_KIN, N=30, T=0.1, n_obs=3)
+        x0, xs, _, obs = scenes.sample_c3(B, N=30, dt=0.1, seed=2000 + rank)
+        obs_kind = _abi.OBSIN_PREDICTED
+        workload = "C3: kinematic bicycle + 3 predicted moving obstacles (MPC_CBF_optimize_kin_pre + Obs_prediction), N=30, batch %d per GPU, cold start" % B
+    elif conf == "C4":
+        cfg = default_config(model=_abi.MODEL_DYN, N=40, T=0.1, n_obs=3)
+        x0, xs, obs = scenes.sample_c4(B, seed=3000 + rank, n_obs=3)
+        workload = "C4: dynamic bicycle (MPC_CBF_optimize_dyn, aligned rows), N=40, 3 static obstacles, batch %d per GPU, cold start" % B
+    else:
+        cfg = default_config(model=_abi.MODEL_KIN, N=30, T=0.1, n_obs=3)
+        x0, xs, obs, _ = scenes.sample_c3(B, N=30, dt=0.1, seed=4000 + rank)
+        workload = "C5: closed loop, %d scenes per GPU x 80 receding-horizon steps, kinematic bicycle + 3 moving obstacles re-predicted every step" % B
     nx, nz, ng = dims(cfg)
-    x0, xs, obs = scenes.sample_c2(B, seed=1000 + rank)
     bs = BatchSolver(cfg, device=local_rank)
+    if conf == "C5":
+        return closed_loop_bench(args, bs, cfg, x0, xs, obs, workload, rank, world)
     d_x0 = bs.device_array((B, nx)).upload(x0)
     d_xs = bs.device_array((B, nx)).upload(xs)
-    d_obs = bs.device_array((B, 1, 6)).upload(obs)
+    d_obs = bs.device_array(obs.shape).upload(obs)
     d_obj = bs.device_array((B,)); d_kkt = bs.device_array((B, 4))
     d_st = bs.device_array((B,), np.int32); d_it = bs.device_array((B,), np.int32)
     if world > 1:   # z lives in a torch tensor so that RCCL can gather it; the solver only sees its raw pointer
@@ -105,7 +153,7 @@ def main():
         d_z = bs.device_array((B, nz)); z_ptr = d_z
 
     def step():
-        bs.solve_device(B, d_x0, d_xs, d_obs, _abi.OBSIN_STATIC, None, z_ptr, d_obj, d_st, d_it, d_kkt)
+        bs.solve_device(B, d_x0, d_xs, d_obs, obs_kind, None, z_ptr, d_obj, d_st, d_it, d_kkt)
         if world > 1:
             bs.sync()                                   # the solve runs on the library's own stream
             dist.all_gather_into_tensor(z_all, z_local)
@@ -140,21 +188,19 @@ def main():
 
     if rank == 0:
         kernel_ms = tm["total_ms"] / max(1, tm["launches"])
-        abytes = algorithmic_bytes_per_solve(nx, nz, 6) * B
+        abytes = algorithmic_bytes_per_solve(nx, nz, int(obs[0].size)) * B
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
         it_ok = iters[status == 0]
-        flops = 56e3 * float(iters.sum())       # ~56 kflop per interior-point iteration at N=30 (kin)
+        flops = (147e3 if cfg.model == _abi.MODEL_DYN else 56e3) * float(iters.sum())   # ~56 kflop (kin N=30) / ~147 kflop (dyn N=40) per iteration
         out = {
             "metric": "mpc_solves_per_sec", "value": solved_all * args.steps / dt_max, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2: kinematic bicycle + 1 static CBF/keep-out obstacle row set (MPC_CBF_optimize_kin), N=30, "
-                                   "T=0.1, batch %d random x0 per GPU, cold start z0=0" % B,
-                       "batch_per_gpu": B, "solved_per_step": solved_all, "failed_per_step": world * B - solved_all,
+            "config": {"workload": workload, "batch_per_gpu": B, "solved_per_step": solved_all, "failed_per_step": world * B - solved_all,
                        "iters_mean_solved": float(it_ok.mean()) if len(it_ok) else None, "iters_max": int(iters.max()),
                        "tol": cfg.tol, "collective": "rccl all_gather of z per step" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "mpcb_kernel_kin<1>", "kernel_ms_avg": kernel_ms,
+                         "traffic": None, "kernel": "mpcb_kernel_%s<%d>" % ("dyn" if cfg.model == _abi.MODEL_DYN else "kin", 1 if cfg.n_obs <= 1 else 3), "kernel_ms_avg": kernel_ms,
                          "algorithmic_bytes_per_launch": abytes,
                          "note": "compulsory I/O is 3072 B/solve; the solve is LDS-resident, bound by FP64 VALU issue and the serial "
                                  "Riccati chain, not by HBM (SURVEY.md F10, DESIGN.md §5)"},
