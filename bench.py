@@ -74,7 +74,6 @@ def closed_loop_bench(args, bs, cfg, x0, xs, obs, workload, rank, world):
     dt = time.perf_counter() - t0
     tm = bs.timing()
     solved = int((r["status"] == 0).sum())
-    h = scenes.ellipse_h(r["x_hist"][:, :, None, :2], r["obs_state"][:, None, :, :])   # margin versus the final obstacle positions only
     out = {"metric": "mpc_solves_per_sec", "value": solved * reps / dt, "unit": "solves/s", "n_gpus": world, "steps": reps, "warmup": args.warmup,
            "ms_per_step": 1e3 * dt / reps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": workload, "scenes_per_gpu": len(x0), "sim_steps": sim_steps, "solved_steps": solved,

@@ -67,23 +67,26 @@ enum KinEnt {
 };
 
 // LDS layout (doubles).  ld = (N+1)|1: odd leading dimension of the [entry][node] tables.
+//   Pst [N+1][PST]   P_k (6x6, row-major) + 4 pad slots that absorb the stores of lanes without a P entry
+//   pst [N+1][8]     p_k (6), slot 6 is a permanent 0.0 (base value of the W accumulation in non-affine lanes), slot 7 pad
+//   fw  [N+1][FWS]   everything the forward roll-out reads for stage k, contiguous: K (2x6), kff (2), a02 a03 a12 a13 a23 b20,
+//                    d0..d3, then 4 pad slots for the K stores of lanes without a K entry
+constexpr int PST = 40, PSS = 8, FWS = 28, FW_KFF = 12, FW_A = 14, FW_D = 20, FW_PAD = 24, WSZ = 64;
 struct Layout {
-  int ld, ent, Pst, pst, Kst, kff, W, q, filt, zbuf, total;
+  int ld, ent, Pst, pst, fw, W, filt, zbuf, total;
 };
 MPCB_HD Layout layout_kin(int N, int nz) {
   Layout L;
-  const int N1 = N + 1, NA = 6, NW = 8;
+  const int N1 = N + 1;
   L.ld = N1 | 1;
   int o = 0;
-  L.ent = o; o += KIN_NENT * L.ld;
-  L.Pst = o; o += N1 * NA * NA;
-  L.pst = o; o += N1 * NA;
-  L.Kst = o; o += N1 * 2 * NA;
-  L.kff = o; o += N1 * 2;
-  L.W = o; o += 2 * NW * NA;         // double-buffered W^T (one buffer per stage parity: no WAR hazard between stages)
-  L.q = o; o += 2 * NW;
+  L.Pst = o; o += N1 * PST;          // first: 16-byte aligned rows for wide LDS reads
+  L.pst = o; o += N1 * PSS;
+  L.fw = o; o += N1 * FWS;
+  L.W = o; o += WSZ;                 // W^T (8 columns x 6) + 16 pad slots
   L.filt = o; o += 2 * FILTER_MAX;
-  L.zbuf = L.Pst;                   // staging of z rows aliases the Riccati storage (used before / after the loop)
+  L.ent = o; o += KIN_NENT * L.ld;
+  L.zbuf = L.Pst;                    // staging of z rows aliases the Riccati storage (used before / after the loop)
   (void)nz;
   L.total = o;
   return L;
@@ -404,17 +407,34 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     if (lo == 5 && hi == 7) return E_H57;
     return E_ZERO;
   };
+  // Column 4 of the stage block belongs to U_prev, whose column of [A B] is zero: W(:,4) = 0 and M(:,4) = H(:,4) need no
+  // arithmetic.  The lanes of that column therefore carry the AFFINE part of the recursion through the same instruction
+  // stream: their "[A B] column" is the defect d, their accumulation starts from p+ (resp. g), so W(:,4) := q and their
+  // M accumulator := m.  No lane computes q or m redundantly.
+  const bool aff = (ej == 4);
   int sABj[NA], sABi[NA];
 #pragma unroll
-  for (int r = 0; r < NA; ++r) { sABj[r] = slotAB(r, ej) * ld; sABi[r] = slotAB(r, ei) * ld; }
+  for (int r = 0; r < NA; ++r) {
+    sABj[r] = (aff ? (r < NX ? E_D0 + r : E_ZERO) : slotAB(r, ej)) * ld;
+    sABi[r] = slotAB(r, ei) * ld;
+  }
   const int sHij = slotH(ei, ej) * ld, sGi = (E_G0 + ei) * ld;
-  const int eiA = ei < NA ? ei : 0;           // clamped row for lanes of the control rows (their W is unused)
+  const int sStart = aff ? sGi : sHij;         // start value of the M accumulation: g_i in the affine lanes, H_ij elsewhere
+  const int eiA = ei < NA ? ei : 0;            // clamped row for lanes of the control rows (their W is unused)
+  const int pvOff = aff ? eiA : 6;             // base of the W accumulation: p+_i in the affine lanes, the permanent 0 elsewhere
+  // store targets; lanes without an entry write into pad slots, so that the sweep has no divergent branches
+  const int wOff = ei < NA ? ej * NA + ei : NW * NA + (lane & 15);
+  const int pOff = (ei < NA && ej < NA) ? ei * NA + ej : NA * NA + (lane & 3);
+  const int psOff = (aff && ei < NA) ? ei : 7;
+  const int kOff = (ej < NA && ei == 0) ? ej : (ej < NA && ei == 1) ? NA + ej : (lane == 62) ? FW_KFF : (lane == 63) ? FW_KFF + 1 : FW_PAD + (lane & 3);
+  const int kSel = (ei == 1) ? 1 : (lane == 62) ? 2 : (lane == 63) ? 3 : 0;   // which of K0j, K1j, kf0, kf1 this lane stores
 
   // constant rows of the entry table
   if (isnode) { ent[E_ZERO * ld + k] = 0.0; ent[E_ONE * ld + k] = 1.0; ent[E_T * ld + k] = T; }
+  // (pst slot 6 = 0.0 is written after the z0 staging below has finished with the aliased region)
 
-  double* Pst = lds + L.Pst; double* pst = lds + L.pst; double* Kst = lds + L.Kst; double* kffs = lds + L.kff;
-  double* Wl = lds + L.W; double* ql = lds + L.q; double* filt = lds + L.filt;
+  double* Pst = lds + L.Pst; double* pst = lds + L.pst; double* fw = lds + L.fw;
+  double* Wl = lds + L.W; double* filt = lds + L.filt;
   int nfilt = 0;
   double theta_max = 0, theta_min = 0;
   double dw_last = 0.0;
@@ -571,6 +591,12 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           for (int i = 0; i < NX; ++i) ent[(E_D0 + i) * ld + k] = dfc[i];
 #pragma unroll
           for (int i = 0; i < NW; ++i) ent[(E_G0 + i) * ld + k] = g[i];
+          double* fk = fw + k * FWS;                     // the same numbers once more, contiguous, for the forward roll-out
+          fk[FW_A + 0] = hasu ? a02 : 0.0; fk[FW_A + 1] = hasu ? a03 : 0.0; fk[FW_A + 2] = hasu ? a12 : 0.0;
+          fk[FW_A + 3] = hasu ? a13 : 0.0; fk[FW_A + 4] = hasu ? a23 : 0.0; fk[FW_A + 5] = hasu ? b20 : 0.0;
+#pragma unroll
+          for (int i = 0; i < NX; ++i) fk[FW_D + i] = dfc[i];
+          pst[k * PSS + 6] = 0.0;
           ent[E_HXY * ld + k] = hxy; ent[E_HPV * ld + k] = hpv; ent[E_HVD * ld + k] = hvd;
           ent[E_H44 * ld + k] = h44; ent[E_H55 * ld + k] = h55; ent[E_H46 * ld + k] = h46; ent[E_H57 * ld + k] = h57;
         }
@@ -588,63 +614,56 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         }
         wv::sync();
         // terminal: P_N = H_N (state block), p_N = g_N
-        if (ei < NA && ej < NA) Pst[N * NA * NA + ei * NA + ej] = ent[sHij + N];
-        if (ei < NA && ej == 0) pst[N * NA + ei] = ent[sGi + N];
+        if (ei < NA && ej < NA) Pst[N * PST + ei * NA + ej] = ent[sHij + N];
+        if (ei < NA && ej == 0) pst[N * PSS + ei] = ent[sGi + N];
         wv::sync();
         // Stage entries (18 table values per lane) do not depend on the recursion: they are prefetched one stage ahead
         // into a second register set (ping-pong, no copies) so that only the P+ row and the W exchange sit on the
         // critical path.  MPCB_SCHED_FENCE keeps the compiler from sinking the batched loads next to their uses.
-        struct StageEnt { double abj[NA], abi[NA], hij, gi, dd[NX]; };
+        struct StageEnt { double abj[NA], abi[NA], start, hmat; };
         auto load_ent = [&](int s, StageEnt& e) {
 #pragma unroll
           for (int r = 0; r < NA; ++r) { e.abj[r] = ent[sABj[r] + s]; e.abi[r] = ent[sABi[r] + s]; }
-          e.hij = ent[sHij + s]; e.gi = ent[sGi + s];
-#pragma unroll
-          for (int r = 0; r < NX; ++r) e.dd[r] = ent[(E_D0 + r) * ld + s];
+          e.start = ent[sStart + s]; e.hmat = ent[sHij + s];
         };
         auto stage = [&](int s, const StageEnt& e, StageEnt& nxt) -> bool {
-          // W = P+ [A B],  q = p+ + P+ d          (lane (i,j): row i of P+, column j of [A B])
-          const double* Pn = Pst + (s + 1) * NA * NA + eiA * NA;
+          // W = P+ [A B | d] (+ p+ in the affine column)      lane (i,j): row i of P+, column j
+          const double* Pn = Pst + (s + 1) * PST + eiA * NA;
           double Pr[NA];
 #pragma unroll
           for (int r = 0; r < NA; ++r) Pr[r] = Pn[r];
-          double qv = pst[(s + 1) * NA + eiA];
+          double w = pst[(s + 1) * PSS + pvOff];
           MPCB_SCHED_FENCE();
-          double w = 0;
 #pragma unroll
           for (int r = 0; r < NA; ++r) w += Pr[r] * e.abj[r];
-#pragma unroll
-          for (int r = 0; r < NX; ++r) qv += Pr[r] * e.dd[r];
-          if (ei < NA) { Wl[ej * NA + ei] = w; if (ej == 0) ql[ei] = qv; }
+          Wl[wOff] = w;
           load_ent(s > 0 ? s - 1 : 0, nxt);                       // prefetch for the next stage, off the critical path
           wv::sync();
-          double Wc[NA], qc[NA];
+          double Wc[NA];
 #pragma unroll
-          for (int r = 0; r < NA; ++r) { Wc[r] = Wl[ej * NA + r]; qc[r] = ql[r]; }
+          for (int r = 0; r < NA; ++r) Wc[r] = Wl[ej * NA + r];
           MPCB_SCHED_FENCE();
-          // M = H + [A B]^T W,  m = g + [A B]^T q
-          double Mij = e.hij, mi = e.gi;
+          // M = H + [A B]^T W; in the affine lanes the same sum is m = g + [A B]^T q
+          double acc = e.start;
 #pragma unroll
-          for (int r = 0; r < NA; ++r) { Mij += e.abi[r] * Wc[r]; mi += e.abi[r] * qc[r]; }
-          // control block Muu (lanes (6,6),(6,7),(7,6),(7,7)) and m_u (lanes (6,*),(7,*)) to every lane
-          const double m11 = wv::bcast(Mij, NA * 8 + NA), m12 = 0.5 * (wv::bcast(Mij, NA * 8 + NA + 1) + wv::bcast(Mij, (NA + 1) * 8 + NA));
-          const double m22 = wv::bcast(Mij, (NA + 1) * 8 + NA + 1);
-          const double mu6 = wv::bcast(mi, NA * 8), mu7 = wv::bcast(mi, (NA + 1) * 8);
+          for (int r = 0; r < NA; ++r) acc += e.abi[r] * Wc[r];
+          const double Mx = aff ? e.hmat : acc;                   // matrix value of this lane (column 4: H itself)
+          // control block Muu (lanes (6,6),(6,7),(7,6),(7,7)) and m_u (affine lanes (6,4),(7,4)) to every lane
+          const double m11 = wv::bcast(Mx, NA * 8 + NA), m12 = 0.5 * (wv::bcast(Mx, NA * 8 + NA + 1) + wv::bcast(Mx, (NA + 1) * 8 + NA));
+          const double m22 = wv::bcast(Mx, (NA + 1) * 8 + NA + 1);
+          const double mu6 = wv::bcast(acc, NA * 8 + 4), mu7 = wv::bcast(acc, (NA + 1) * 8 + 4);
           // rows 6,7 of M at column j and at column i (M is symmetric up to rounding)
-          const double M6j = wv::shfl(Mij, NA * 8 + ej), M7j = wv::shfl(Mij, (NA + 1) * 8 + ej);
-          const double M6i = wv::shfl(Mij, NA * 8 + ei), M7i = wv::shfl(Mij, (NA + 1) * 8 + ei);
+          const double M6j = wv::shfl(Mx, NA * 8 + ej), M7j = wv::shfl(Mx, (NA + 1) * 8 + ej);
+          const double M6i = wv::shfl(Mx, NA * 8 + ei), M7i = wv::shfl(Mx, (NA + 1) * 8 + ei);
           const double det = m11 * m22 - m12 * m12;
           if (!(m11 > 0) || !(det > 1e-14 * m11 * m22) || !isfinite(det)) return false;
           const double idet = wv::rcp(det);
           const double i11 = m22 * idet, i12 = -m12 * idet, i22 = m11 * idet;
           const double kf0 = -(i11 * mu6 + i12 * mu7), kf1 = -(i12 * mu6 + i22 * mu7);
           const double K0j = -(i11 * M6j + i12 * M7j), K1j = -(i12 * M6j + i22 * M7j);
-          if (ei < NA && ej < NA) {
-            Pst[s * NA * NA + ei * NA + ej] = Mij + M6i * K0j + M7i * K1j;
-            if (ei == 0) { Kst[s * 2 * NA + ej] = K0j; Kst[s * 2 * NA + NA + ej] = K1j; }
-            if (ej == 0) pst[s * NA + ei] = mi + M6i * kf0 + M7i * kf1;
-          }
-          if (lane == 0) { kffs[s * 2] = kf0; kffs[s * 2 + 1] = kf1; }
+          Pst[s * PST + pOff] = Mx + M6i * K0j + M7i * K1j;                 // P_s (lanes i,j < 6), pad elsewhere
+          pst[s * PSS + psOff] = acc + M6i * kf0 + M7i * kf1;               // p_s (affine lanes), pad slot 7 elsewhere
+          fw[s * FWS + kOff] = kSel == 0 ? K0j : kSel == 1 ? K1j : kSel == 2 ? kf0 : kf1;
           wv::sync();
           return true;
         };
@@ -674,13 +693,12 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         // 24 table values per stage, none of them on the recursion: prefetched one stage ahead (ping-pong registers)
         struct FwEnt { double K[2 * NA], kf0, kf1, a02, a03, a12, a13, a23, b20, d0, d1, d2, d3; };
         auto load_fw = [&](int s, FwEnt& f) {
-          const double* Ks = Kst + s * 2 * NA;
+          const double* q = fw + s * FWS;                // 24 contiguous doubles, uniform address: wide LDS reads
 #pragma unroll
-          for (int r = 0; r < 2 * NA; ++r) f.K[r] = Ks[r];
-          f.kf0 = kffs[s * 2]; f.kf1 = kffs[s * 2 + 1];
-          f.a02 = ent[E_A02 * ld + s]; f.a03 = ent[E_A03 * ld + s]; f.a12 = ent[E_A12 * ld + s]; f.a13 = ent[E_A13 * ld + s];
-          f.a23 = ent[E_A23 * ld + s]; f.b20 = ent[E_B20 * ld + s];
-          f.d0 = ent[E_D0 * ld + s]; f.d1 = ent[E_D1 * ld + s]; f.d2 = ent[E_D2 * ld + s]; f.d3 = ent[E_D3 * ld + s];
+          for (int r = 0; r < 2 * NA; ++r) f.K[r] = q[r];
+          f.kf0 = q[FW_KFF]; f.kf1 = q[FW_KFF + 1];
+          f.a02 = q[FW_A]; f.a03 = q[FW_A + 1]; f.a12 = q[FW_A + 2]; f.a13 = q[FW_A + 3]; f.a23 = q[FW_A + 4]; f.b20 = q[FW_A + 5];
+          f.d0 = q[FW_D]; f.d1 = q[FW_D + 1]; f.d2 = q[FW_D + 2]; f.d3 = q[FW_D + 3];
         };
         double dx0 = 0, dx1 = 0, dx2 = 0, dx3 = 0, dx4 = 0, dx5 = 0;
         auto fstage = [&](int s, const FwEnt& f, FwEnt& nxt) {
@@ -709,11 +727,11 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       // costate of the full step: lamF_k = P_k [dX_k; dU_{k-1}] + p_k  (node-parallel)
       double lamF[NX] = {0, 0, 0, 0};
       if (xnode) {
-        const double* Pk = Pst + k * NA * NA;
+        const double* Pk = Pst + k * PST;
         const double dxa[NA] = {dX[0], dX[1], dX[2], dX[3], dUp0, dUp1};
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-          double s = pst[k * NA + i];
+          double s = pst[k * PSS + i];
 #pragma unroll
           for (int r = 0; r < NA; ++r) s += Pk[i * NA + r] * dxa[r];
           lamF[i] = s;
