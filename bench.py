@@ -109,7 +109,8 @@ def main():
     from mpc_motion_planning_amd.solver import BatchSolver, default_config, dims
 
     dist = None; torch = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("MPCB_BENCH_FORCE_DIST") == "1"    # the env switch rehearses the N > 1 plumbing with one rank
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -144,7 +145,7 @@ def main():
     d_obs = bs.device_array(obs.shape).upload(obs)
     d_obj = bs.device_array((B,)); d_kkt = bs.device_array((B, 4))
     d_st = bs.device_array((B,), np.int32); d_it = bs.device_array((B,), np.int32)
-    if world > 1:   # z lives in a torch tensor so that RCCL can gather it; the solver only sees its raw pointer
+    if use_dist:    # z lives in a torch tensor so that RCCL can gather it; the solver only sees its raw pointer
         z_local = torch.empty((B, nz), dtype=torch.float64, device="cuda")
         z_all = torch.empty((world * B, nz), dtype=torch.float64, device="cuda")
         z_ptr = z_local.data_ptr()
@@ -153,13 +154,13 @@ def main():
 
     def step():
         bs.solve_device(B, d_x0, d_xs, d_obs, obs_kind, None, z_ptr, d_obj, d_st, d_it, d_kkt)
-        if world > 1:
+        if use_dist:
             bs.sync()                                   # the solve runs on the library's own stream
             dist.all_gather_into_tensor(z_all, z_local)
 
     def fence():
         bs.sync()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -177,7 +178,7 @@ def main():
 
     status = d_st.download(); iters = d_it.download()
     solved = int((status == 0).sum())
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt, float(solved), float(tm["total_ms"])], dtype=torch.float64, device="cuda")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
@@ -197,7 +198,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "batch_per_gpu": B, "solved_per_step": solved_all, "failed_per_step": world * B - solved_all,
                        "iters_mean_solved": float(it_ok.mean()) if len(it_ok) else None, "iters_max": int(iters.max()),
-                       "tol": cfg.tol, "collective": "rccl all_gather of z per step" if world > 1 else "none"},
+                       "tol": cfg.tol, "collective": "rccl all_gather of z per step" if use_dist else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "mpcb_kernel_%s<%d>" % ("dyn" if cfg.model == _abi.MODEL_DYN else "kin", 1 if cfg.n_obs <= 1 else 3), "kernel_ms_avg": kernel_ms,
                          "algorithmic_bytes_per_launch": abytes,
@@ -210,7 +211,9 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, x0, xs, obs)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
+        if rank == 0 and world == 1:      # rehearsal: the gathered block must equal what the solver wrote
+            assert torch.equal(z_all[:B], z_local), "all_gather result differs from the solver output"
         dist.barrier()
         dist.destroy_process_group()
 
