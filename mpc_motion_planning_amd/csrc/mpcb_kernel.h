@@ -632,10 +632,11 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           double Pr[NA];
 #pragma unroll
           for (int r = 0; r < NA; ++r) Pr[r] = Pn[r];
-          double w = pst[(s + 1) * PSS + pvOff];
+          const double w0 = pst[(s + 1) * PSS + pvOff];
           MPCB_SCHED_FENCE();
-#pragma unroll
-          for (int r = 0; r < NA; ++r) w += Pr[r] * e.abj[r];
+          // two partial sums: halves the dependent FMA chain on the critical path of the recursion
+          const double w = fma(Pr[4], e.abj[4], fma(Pr[2], e.abj[2], fma(Pr[0], e.abj[0], w0))) +
+                           fma(Pr[5], e.abj[5], fma(Pr[3], e.abj[3], Pr[1] * e.abj[1]));
           Wl[wOff] = w;
           load_ent(s > 0 ? s - 1 : 0, nxt);                       // prefetch for the next stage, off the critical path
           wv::sync();
@@ -644,9 +645,8 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           for (int r = 0; r < NA; ++r) Wc[r] = Wl[ej * NA + r];
           MPCB_SCHED_FENCE();
           // M = H + [A B]^T W; in the affine lanes the same sum is m = g + [A B]^T q
-          double acc = e.start;
-#pragma unroll
-          for (int r = 0; r < NA; ++r) acc += e.abi[r] * Wc[r];
+          const double acc = fma(e.abi[4], Wc[4], fma(e.abi[2], Wc[2], fma(e.abi[0], Wc[0], e.start))) +
+                             fma(e.abi[5], Wc[5], fma(e.abi[3], Wc[3], e.abi[1] * Wc[1]));
           const double Mx = aff ? e.hmat : acc;                   // matrix value of this lane (column 4: H itself)
           // control block Muu (lanes (6,6),(6,7),(7,6),(7,7)) and m_u (affine lanes (6,4),(7,4)) to every lane
           const double m11 = wv::bcast(Mx, NA * 8 + NA), m12 = 0.5 * (wv::bcast(Mx, NA * 8 + NA + 1) + wv::bcast(Mx, (NA + 1) * 8 + NA));
@@ -656,7 +656,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           const double M6j = wv::shfl(Mx, NA * 8 + ej), M7j = wv::shfl(Mx, (NA + 1) * 8 + ej);
           const double M6i = wv::shfl(Mx, NA * 8 + ei), M7i = wv::shfl(Mx, (NA + 1) * 8 + ei);
           const double det = m11 * m22 - m12 * m12;
-          if (!(m11 > 0) || !(det > 1e-14 * m11 * m22) || !isfinite(det)) return false;
+          const bool okpd = (m11 > 0) && (det > 1e-14 * m11 * m22) && isfinite(det);   // wave-uniform
           const double idet = wv::rcp(det);
           const double i11 = m22 * idet, i12 = -m12 * idet, i22 = m11 * idet;
           const double kf0 = -(i11 * mu6 + i12 * mu7), kf1 = -(i12 * mu6 + i22 * mu7);
@@ -665,7 +665,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           pst[s * PSS + psOff] = acc + M6i * kf0 + M7i * kf1;               // p_s (affine lanes), pad slot 7 elsewhere
           fw[s * FWS + kOff] = kSel == 0 ? K0j : kSel == 1 ? K1j : kSel == 2 ? kf0 : kf1;
           wv::sync();
-          return true;
+          return okpd;                                   // a failed stage leaves garbage behind; the sweep is repeated with a larger delta_w
         };
         bool pd = true;
         {
@@ -673,9 +673,10 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           load_ent(N - 1, eA);
           int s = N - 1;
 #pragma clang loop unroll(disable)
-          for (; s >= 1; s -= 2) {
-            if (!stage(s, eA, eB)) { pd = false; break; }
-            if (!stage(s - 1, eB, eA)) { pd = false; break; }
+          for (; s >= 1 && pd; s -= 2) {
+            const bool p1 = stage(s, eA, eB);
+            const bool p2 = stage(s - 1, eB, eA);
+            pd = p1 && p2;
           }
           if (pd && s == 0) pd = stage(0, eA, eB);
         }
