@@ -32,6 +32,38 @@ class ModelFunction:
         return DM(model_rhs(self._cfg, np.asarray(x, dtype=np.float64).reshape(-1), np.asarray(u, dtype=np.float64).reshape(-1)))
 
 
+def nlp_constraints(cfg, z, x0, obs, obs_kind):
+    """g(z) in the reference's row order (kin.py:190-247 / dyn.py:215-243), evaluated on the host for the result dict.
+    Obstacle rows are reported as h (the dyn reference's row is sqrt(h))."""
+    N, nx = cfg.N, cfg.nx()
+    z = np.asarray(z, dtype=np.float64).reshape(-1)
+    U = z[:2 * N].reshape(N, 2); X = z[2 * N:].reshape(N + 1, nx)
+    f = np.stack([model_rhs(cfg, X[i], U[i]) for i in range(N)])
+    dyn_rows = X[1:] - (X[:-1] + cfg.T * f)
+    rate_cols = [c for c in range(2) if np.isfinite(cfg.du_lo[c]) or np.isfinite(cfg.du_hi[c])]
+    rows = [X[0] - np.asarray(x0, dtype=np.float64).reshape(-1)]
+    if cfg.rate_interleaved:
+        for i in range(N):
+            rows.append(dyn_rows[i])
+            if i > 0:
+                rows.append(np.array([U[i, c] - U[i - 1, c] for c in rate_cols]))
+    else:
+        rows.append(dyn_rows.reshape(-1))
+        for c in rate_cols:
+            rows.append(U[1:, c] - U[:-1, c])
+    if cfg.n_obs:
+        o = np.asarray(obs, dtype=np.float64).reshape(-1)
+        last = N if cfg.obs_terminal else N - 1
+        for i in range(last + 1):
+            node = i if cfg.obs_mode == _abi.OBS_KEEPOUT else i + 1
+            for j in range(cfg.n_obs):
+                q = o[(j * (N + 1) + i) * 6:(j * (N + 1) + i) * 6 + 6] if obs_kind == _abi.OBSIN_PREDICTED else o[j * 6:j * 6 + 6]
+                sx = cfg.obs_sx_fixed if cfg.obs_sx_fixed > 0 else cfg.ego_hl + q[4] / 2 + cfg.safe_disl
+                sy = cfg.obs_sy_fixed if cfg.obs_sy_fixed > 0 else cfg.ego_hw + q[5] / 2 + cfg.safe_disw
+                rows.append(np.array([(X[node, 0] - q[0]) ** 2 / sx ** 2 + (X[node, 1] - q[1]) ** 2 / sy ** 2 - 1.0]))
+    return np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1) for r in rows])
+
+
 class NlpSolver:
     """What `optimize_problem` returns: callable like the object `ca.nlpsol(...)` gives (kin.py:254)."""
 
@@ -59,7 +91,7 @@ class NlpSolver:
                        "iter_count": int(r["iters"][0]), "status_code": st, "kkt": r["kkt"][0].copy()}
         self._owner.last_stats = self._stats
         return {"x": DM(r["z"][0]), "f": DM(r["obj"][0]), "lam_g": DM(r["lam_g"][0]), "lam_x": DM(r["lam_x"][0]),
-                "lam_p": DM(np.zeros(2 * nx)), "g": DM(np.zeros(bs.ng))}
+                "lam_p": DM(np.zeros(2 * nx)), "g": DM(nlp_constraints(bs.cfg, r["z"][0], pv[:nx], self._obs, self._obs_kind))}
 
     def stats(self):
         return dict(self._stats)

@@ -886,15 +886,20 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   }
 
   // ----- outputs (reference ordering), staged through LDS for coalesced stores ----------------------------------
+  // `ko` = k behind an optimisation barrier: the LDS addresses of the z staging are re-formed here instead of being kept
+  // live (and spilled) from the identical expressions at kernel start — hipcc 7.2 mis-reloaded such a spilled address in the
+  // dyn<3> build (lanes >= 1 wrote their X rows to zbuf[0..5]).
+  const int ko = wv::opaque(k);
+  const int lo = wv::opaque(lane);      // same for the lane index of the coalesced copy loops
   wv::sync();
-  if (hasu) { zbuf[NU * k] = U[0]; zbuf[NU * k + 1] = U[1]; }
+  if (hasu) { zbuf[NU * ko] = U[0]; zbuf[NU * ko + 1] = U[1]; }
   if (isnode) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) zbuf[NU * N + NX * k + i] = X[i];
+    for (int i = 0; i < NX; ++i) zbuf[NU * N + NX * ko + i] = X[i];
   }
   wv::sync();
-  for (int i = lane; i < nz; i += 64) a.z[(size_t)b * nz + i] = zbuf[i];
-  if (lane == 0) {
+  for (int i = lo; i < nz; i += 64) a.z[(size_t)b * nz + i] = zbuf[i];
+  if (lo == 0) {
     if (a.obj) a.obj[b] = fval;
     if (a.status) a.status[b] = status;
     if (a.iters) a.iters[b] = iters;
@@ -902,14 +907,14 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   }
   if (a.want_mult && a.lam_x) {
     wv::sync();
-    for (int i = lane; i < nz; i += 64) zbuf[i] = 0.0;
+    for (int i = lo; i < nz; i += 64) zbuf[i] = 0.0;
     wv::sync();
-    if (bu0_on) zbuf[NU * k] = -item_y(qU0, iU0) / os;
-    if (bu1_on) zbuf[NU * k + 1] = -item_y(qU1, iU1) / os;
-    if (by_on) zbuf[NU * N + NX * k + 1] = -item_y(qY, iY) / os;
-    if (bv_on) zbuf[NU * N + NX * k + 3] = -item_y(qV, iV) / os;
+    if (bu0_on) zbuf[NU * ko] = -item_y(qU0, iU0) / os;
+    if (bu1_on) zbuf[NU * ko + 1] = -item_y(qU1, iU1) / os;
+    if (by_on) zbuf[NU * N + NX * ko + 1] = -item_y(qY, iY) / os;
+    if (bv_on) zbuf[NU * N + NX * ko + 3] = -item_y(qV, iV) / os;
     wv::sync();
-    for (int i = lane; i < nz; i += 64) a.lam_x[(size_t)b * nz + i] = zbuf[i];
+    for (int i = lo; i < nz; i += 64) a.lam_x[(size_t)b * nz + i] = zbuf[i];
   }
   if (a.want_mult && a.lam_g) {
     // rows: [X_0 - P](NX), dynamics (NX*N), rate (N-1 if on), obstacles (rows * nobs)   kin.py:190-247

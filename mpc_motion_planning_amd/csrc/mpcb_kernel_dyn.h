@@ -4,8 +4,10 @@
 // (model :156-170, cost :189-225, dynamics rows :226-228, rate rows on both controls :229-231, obstacle rows at
 // all N+1 nodes :238-243, boxes :85-110).  Same algorithm and wave mapping as mpcb_kernel.h (lane k = node k for
 // everything lane-parallel); the differences are sizes and the model:
-//   * nx = 6, augmented state 8, stage block 10x10 = 100 entries -> TWO entries per lane in the Riccati sweep,
-//     M is exchanged through LDS (3 LDS round trips per stage);
+//   * nx = 6, augmented state 8: the 8x8 STATE block of the stage is one entry per lane; the two control rows/columns
+//     of the 10x10 stage block have the fixed patterns (0,0,0,0,b4,b5,1,0) and (0,0,0,T,0,0,0,1) in [A B] and are
+//     computed with explicit formulas by the lanes of rows 6,7 (whose own rows of [A B] are zero); the affine part of
+//     the recursion rides in column 6.  Same 2 LDS round trips per stage as the kinematic kernel;
 //   * closed-form first and second derivatives of the tyre model (checked against the oracle's forward-mode AD);
 //   * boxes on y, vx, vy; rate rows on steering AND acceleration; obstacle rows of the form h >= obs_hmin.
 // The reference's own bounds lists for this model are mis-aligned with its rows; the rows here are
@@ -28,22 +30,23 @@ enum DynEnt {
   DYN_NENT
 };
 
-struct LayoutDyn { int ld, ent, Pst, pst, Kst, kff, W, q, M, m, filt, zbuf, total; };
+// LDS layout (doubles):
+//   Pst [N+1][64]  P_k (8x8)          pst [N+1][10]  p_k (8), slot 8 = permanent 0.0, slot 9 pad
+//   fw  [N+1][DFWS] per-stage numbers of the forward roll-out, contiguous: K (2x8), kff (2), the 14 A entries, b4 b5, d (6), pad
+constexpr int DPSS = 10, DFWS = 44, DFW_KFF = 16, DFW_A = 18, DFW_B = 32, DFW_D = 34, DFW_PAD = 40, DWSZ = 64, DWU = 16 + 16;
+struct LayoutDyn { int ld, ent, Pst, pst, fw, W, Wu, filt, zbuf, total; };
 MPCB_HD LayoutDyn layout_dyn(int N) {
   LayoutDyn L;
-  const int N1 = N + 1, NA = 8, NW = 10;
+  const int N1 = N + 1, NA = 8;
   L.ld = N1 | 1;
   int o = 0;
-  L.ent = o; o += DYN_NENT * L.ld;
   L.Pst = o; o += N1 * NA * NA;
-  L.pst = o; o += N1 * NA;
-  L.Kst = o; o += N1 * 2 * NA;
-  L.kff = o; o += N1 * 2;
-  L.W = o; o += NW * NA;
-  L.q = o; o += NW;
-  L.M = o; o += NW * NW;
-  L.m = o; o += NW + 2;
+  L.pst = o; o += N1 * DPSS;
+  L.fw = o; o += N1 * DFWS;
+  L.W = o; o += DWSZ;
+  L.Wu = o; o += DWU;
   L.filt = o; o += 2 * FILTER_MAX;
+  L.ent = o; o += DYN_NENT * L.ld;
   L.zbuf = L.Pst;
   L.total = o;
   return L;
@@ -126,7 +129,7 @@ MPCB_DEV void dyn_hess(const mpcb_config& c, const double* X, const DynEval& e, 
 template <int NOBS>
 MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   using namespace mpcbk;
-  constexpr int NX = 6, NA = 8, NW = 10, NOB = NOBS > 0 ? NOBS : 1, NSLOT = 2;
+  constexpr int NX = 6, NA = 8, NW = 10, NOB = NOBS > 0 ? NOBS : 1;
   const mpcb_config& c = a.cfg;
   const int N = c.N, lane = wv::lane(), k = lane;
   const int nz = a.nz, nobs = c.n_obs;
@@ -276,7 +279,6 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   double mu = c.mu_init, tau = fmax(TAU_MIN, 1.0 - mu);
   double dfc[NX] = {0, 0, 0, 0, 0, 0};
   double theta = 0, fval = 0, logsum = 0;
-  DynEval ev;
 
   auto eval_lane = [&](const double* Xa, const double* Ua, double sR0a, double sR1a, const double* sOa, const DynEval& e,
                        double* dfa, double& rR0a, double& rR1a, double* rOa, double& up0, double& up1, double& th, double& fl, double& prod) {
@@ -330,7 +332,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
     n_lam = (double)(NX * N);
   }
 
-  // ----- Riccati lane constants: two entries (i,j) of the 10x10 stage block per lane ---------------------------------
+  // ----- Riccati lane constants: lane = entry (i,j) of the 8x8 state block [X, U_prev]; the control rows ride along ---------------------------------
   auto slotAB = [&](int r, int col) -> int {
     if (r < NX) {
       if (col < NX) {
@@ -361,21 +363,32 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       default: return DE_ZERO;
     }
   };
-  int ei[NSLOT], ej[NSLOT], sHij[NSLOT], sGi[NSLOT], sABj[NSLOT][NA], sABi[NSLOT][NA];
-  bool ev_[NSLOT];
+  // Block form of the stage:  state block (8x8, one entry per lane) + control rows/columns (2x8 + 2x2) computed by the
+  // lanes of rows 6,7 (U_prev rows, whose own [A B] rows are zero) with explicit formulas, because the control columns of
+  // [A B] are (0,0,0,0,b4,b5,1,0) and (0,0,0,T,0,0,0,1).  Column 6 (U_prev, zero column of [A B]) carries the affine part.
+  const int ei = lane >> 3, ej = lane & 7;
+  const bool aff = (ej == 6);
+  const int cU = ei & 1;                         // control index of the rows 6,7 lanes (and of the odd / even W_u pattern)
+  int sABj[NX], sABi[NX];
 #pragma unroll
-  for (int t = 0; t < NSLOT; ++t) {
-    const int e = lane + 64 * t;
-    ev_[t] = e < NW * NW;
-    ei[t] = ev_[t] ? e / NW : 0; ej[t] = ev_[t] ? e % NW : 0;
-    sHij[t] = slotH(ei[t], ej[t]) * ld; sGi[t] = (DE_G0 + ei[t]) * ld;
-#pragma unroll
-    for (int r = 0; r < NA; ++r) { sABj[t][r] = slotAB(r, ej[t]) * ld; sABi[t][r] = slotAB(r, ei[t]) * ld; }
+  for (int r = 0; r < NX; ++r) {
+    sABj[r] = (aff ? DE_D0 + r : slotAB(r, ej)) * ld;
+    sABi[r] = slotAB(r, ei) * ld;
   }
+  const int sHij = slotH(ei, ej) * ld;
+  const int sStart = (aff ? DE_G0 + ei : slotH(ei, ej)) * ld;
+  const int sStartU = (ei >= 6 ? (aff ? DE_G8 + cU : slotH(8 + cU, ej)) : DE_ZERO) * ld;     // start of M_ux(c, j) / m_u(c)
+  const int sHU = (ei >= 6 ? slotH(8 + cU, ej) : DE_ZERO) * ld;                               // matrix value H(8+c, j)
+  const int sStartUU = ((ei >= 6 && ej < 2) ? slotH(8 + cU, 8 + ej) : DE_ZERO) * ld;          // H(8+c, 8+c')
+  const int pvOff = aff ? ei : 8;
+  const int wuOff = ej < 2 ? ej * NA + ei : 16 + (lane & 15);
+  const int psOff = aff ? ei : 9;
+  const int kOff = (ei == 0) ? ej : (ei == 1) ? NA + ej : (lane == 62) ? DFW_KFF : (lane == 63) ? DFW_KFF + 1 : DFW_PAD + (lane & 3);
+  const int kSel = (ei == 1) ? 1 : (lane == 62) ? 2 : (lane == 63) ? 3 : 0;
   if (isnode) { ent[DE_ZERO * ld + k] = 0.0; ent[DE_ONE * ld + k] = 1.0; ent[DE_T * ld + k] = T; }
 
-  double* Pst = lds + L.Pst; double* pst = lds + L.pst; double* Kst = lds + L.Kst; double* kffs = lds + L.kff;
-  double* Wl = lds + L.W; double* ql = lds + L.q; double* Ml = lds + L.M; double* ml = lds + L.m; double* filt = lds + L.filt;
+  double* Pst = lds + L.Pst; double* pst = lds + L.pst; double* fw = lds + L.fw;
+  double* Wl = lds + L.W; double* WuL = lds + L.Wu; double* filt = lds + L.filt;
   int nfilt = 0;
   double theta_max = 0, theta_min = 0, dw_last = 0.0;
   const double mu_floor = c.tol / (K_EPS + 1.0);
@@ -383,7 +396,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
 
   if (status != MPCB_ST_INFEASIBLE_X0) {
     {
-      dyn_eval(c, X, U, ev);
+      DynEval ev; dyn_eval(c, X, U, ev);
       double th, fl, prod;
       eval_lane(X, U, sR0, sR1, sO, ev, dfc, rR0, rR1, rO, Up0, Up1, th, fl, prod);
       double sv[3] = {th, fl, log(prod)};
@@ -397,6 +410,8 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
 
 #pragma clang loop unroll(disable)
     for (iters = 0;; ++iters) {
+      // tyre forces and trig at the iterate are recomputed here rather than kept across the line search (13 doubles/lane)
+      DynEval ev; dyn_eval(c, X, U, ev);
       DynJac J; dyn_jac(c, X, ev, J);
       double ln[NX];
 #pragma unroll
@@ -534,6 +549,14 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           for (int i = 0; i < NX; ++i) ent[(DE_D0 + i) * ld + k] = dfc[i];
 #pragma unroll
           for (int i = 0; i < NW; ++i) ent[(DE_G0 + i) * ld + k] = g[i];
+          double* fk = fw + k * DFWS;
+          const double ja[14] = {J.a02, J.a03, J.a04, J.a12, J.a13, J.a14, J.a34, J.a35, J.a43, J.a44, J.a45, J.a53, J.a54, J.a55};
+#pragma unroll
+          for (int i = 0; i < 14; ++i) fk[DFW_A + i] = z * ja[i];
+          fk[DFW_B] = z * J.b4; fk[DFW_B + 1] = z * J.b5;
+#pragma unroll
+          for (int i = 0; i < NX; ++i) fk[DFW_D + i] = dfc[i];
+          pst[k * DPSS + 8] = 0.0;
           ent[DE_H01 * ld + k] = h01; ent[DE_H23 * ld + k] = Hh.h23; ent[DE_H24 * ld + k] = Hh.h24;
           ent[DE_H34 * ld + k] = Hh.h34; ent[DE_H35 * ld + k] = Hh.h35; ent[DE_H45 * ld + k] = Hh.h45;
           ent[DE_H38 * ld + k] = Hh.h38; ent[DE_H48 * ld + k] = Hh.h48; ent[DE_H58 * ld + k] = Hh.h58;
@@ -552,58 +575,74 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           ent[DE_H88 * ld + k] = hd[8] + du_; ent[DE_H99 * ld + k] = hd[9] + du_;
         }
         wv::sync();
-#pragma unroll
-        for (int t = 0; t < NSLOT; ++t) if (ev_[t] && ei[t] < NA && ej[t] < NA) {
-          Pst[N * NA * NA + ei[t] * NA + ej[t]] = ent[sHij[t] + N];
-          if (ej[t] == 0) pst[N * NA + ei[t]] = ent[sGi[t] + N];
-        }
+        // terminal: P_N = H_N (state block), p_N = g_N
+        Pst[N * NA * NA + ei * NA + ej] = ent[sHij + N];
+        if (ej == 0) pst[N * DPSS + ei] = ent[(DE_G0 + ei) * ld + N];
         wv::sync();
-        bool pd = true;
-#pragma clang loop unroll(disable)
-        for (int s = N - 1; s >= 0; --s) {
-          const double* Pn = Pst + (s + 1) * NA * NA;
+        struct StageEnt { double abj[NX], abi[NX], start, hmat, startU, hU, startUU, b4, b5; };
+        auto load_ent = [&](int s, StageEnt& e) {
 #pragma unroll
-          for (int t = 0; t < NSLOT; ++t) if (ev_[t] && ei[t] < NA) {
-            const double* Pr = Pn + ei[t] * NA;
-            double w = 0;
+          for (int r = 0; r < NX; ++r) { e.abj[r] = ent[sABj[r] + s]; e.abi[r] = ent[sABi[r] + s]; }
+          e.start = ent[sStart + s]; e.hmat = ent[sHij + s];
+          e.startU = ent[sStartU + s]; e.hU = ent[sHU + s]; e.startUU = ent[sStartUU + s];
+          e.b4 = ent[DE_B4 * ld + s]; e.b5 = ent[DE_B5 * ld + s];
+        };
+        auto stage = [&](int s, const StageEnt& e, StageEnt& nxt) -> bool {
+          const double* Pn = Pst + (s + 1) * NA * NA + ei * NA;
+          double Pr[NA];
 #pragma unroll
-            for (int r = 0; r < NA; ++r) w += Pr[r] * ent[sABj[t][r] + s];
-            Wl[ej[t] * NA + ei[t]] = w;
-            if (ej[t] == 0) {
-              double qv = pst[(s + 1) * NA + ei[t]];
-#pragma unroll
-              for (int r = 0; r < NX; ++r) qv += Pr[r] * ent[(DE_D0 + r) * ld + s];
-              ql[ei[t]] = qv;
-            }
-          }
+          for (int r = 0; r < NA; ++r) Pr[r] = Pn[r];
+          const double w0 = pst[(s + 1) * DPSS + pvOff];
+          MPCB_SCHED_FENCE();
+          // W_x = P+ [A | d] over the state columns (rows 6,7 of [A B] are zero), W_u = P+ B over the two control columns
+          const double w = fma(Pr[4], e.abj[4], fma(Pr[2], e.abj[2], fma(Pr[0], e.abj[0], w0))) +
+                           fma(Pr[5], e.abj[5], fma(Pr[3], e.abj[3], Pr[1] * e.abj[1]));
+          const double wu = (ej & 1) ? fma(T, Pr[3], Pr[7]) : fma(e.b4, Pr[4], fma(e.b5, Pr[5], Pr[6]));
+          Wl[ej * NA + ei] = w;
+          WuL[wuOff] = wu;
+          load_ent(s > 0 ? s - 1 : 0, nxt);
           wv::sync();
+          double Wc[NA], Wuc[NA];
 #pragma unroll
-          for (int t = 0; t < NSLOT; ++t) if (ev_[t]) {
-            double Mij = ent[sHij[t] + s], mi = ent[sGi[t] + s];
+          for (int r = 0; r < NA; ++r) Wc[r] = Wl[ej * NA + r];
 #pragma unroll
-            for (int r = 0; r < NA; ++r) { const double ab = ent[sABi[t][r] + s]; Mij += ab * Wl[ej[t] * NA + r]; mi += ab * ql[r]; }
-            Ml[ei[t] * NW + ej[t]] = Mij;
-            if (ej[t] == 0) ml[ei[t]] = mi;
-          }
-          wv::sync();
-          const double m11 = Ml[NA * NW + NA], m12 = 0.5 * (Ml[NA * NW + NA + 1] + Ml[(NA + 1) * NW + NA]), m22 = Ml[(NA + 1) * NW + NA + 1];
+          for (int r = 3; r < NA; ++r) Wuc[r] = WuL[(ej & 1) * NA + r];
+          MPCB_SCHED_FENCE();
+          // M_xx = H_xx + A^T W_x  (affine lanes: m_x);  M_ux(c,:) = H_ux + B_c^T W_x (affine lanes: m_u);  M_uu = H_uu + B^T W_u
+          const double acc = fma(e.abi[4], Wc[4], fma(e.abi[2], Wc[2], fma(e.abi[0], Wc[0], e.start))) +
+                             fma(e.abi[5], Wc[5], fma(e.abi[3], Wc[3], e.abi[1] * Wc[1]));
+          const double mux = e.startU + (cU ? fma(T, Wc[3], Wc[7]) : fma(e.b4, Wc[4], fma(e.b5, Wc[5], Wc[6])));
+          const double muu = e.startUU + (cU ? fma(T, Wuc[3], Wuc[7]) : fma(e.b4, Wuc[4], fma(e.b5, Wuc[5], Wuc[6])));
+          const double Mx = aff ? e.hmat : acc;
+          const double MxU = aff ? e.hU : mux;
+          const double m11 = wv::bcast(muu, 48), m12 = 0.5 * (wv::bcast(muu, 49) + wv::bcast(muu, 56)), m22 = wv::bcast(muu, 57);
+          const double mu8 = wv::bcast(mux, 54), mu9 = wv::bcast(mux, 62);
+          const double M8j = wv::shfl(MxU, 48 + ej), M9j = wv::shfl(MxU, 56 + ej);
+          const double M8i = wv::shfl(MxU, 48 + ei), M9i = wv::shfl(MxU, 56 + ei);
           const double det = m11 * m22 - m12 * m12;
-          if (!(m11 > 0) || !(det > 1e-14 * m11 * m22) || !isfinite(det)) { pd = false; break; }
-          const double idet = 1.0 / det;
+          const bool okpd = (m11 > 0) && (det > 1e-14 * m11 * m22) && isfinite(det);
+          const double idet = wv::rcp(det);
           const double i11 = m22 * idet, i12 = -m12 * idet, i22 = m11 * idet;
-          const double mu8 = ml[NA], mu9 = ml[NA + 1];
           const double kf0 = -(i11 * mu8 + i12 * mu9), kf1 = -(i12 * mu8 + i22 * mu9);
-#pragma unroll
-          for (int t = 0; t < NSLOT; ++t) if (ev_[t] && ei[t] < NA && ej[t] < NA) {
-            const double M8j = Ml[NA * NW + ej[t]], M9j = Ml[(NA + 1) * NW + ej[t]];
-            const double Mi8 = Ml[ei[t] * NW + NA], Mi9 = Ml[ei[t] * NW + NA + 1];
-            const double K0j = -(i11 * M8j + i12 * M9j), K1j = -(i12 * M8j + i22 * M9j);
-            Pst[s * NA * NA + ei[t] * NA + ej[t]] = Ml[ei[t] * NW + ej[t]] + Mi8 * K0j + Mi9 * K1j;
-            if (ei[t] == 0) { Kst[s * 2 * NA + ej[t]] = K0j; Kst[s * 2 * NA + NA + ej[t]] = K1j; }
-            if (ej[t] == 0) pst[s * NA + ei[t]] = ml[ei[t]] + Mi8 * kf0 + Mi9 * kf1;
-          }
-          if (lane == 0) { kffs[s * 2] = kf0; kffs[s * 2 + 1] = kf1; }
+          const double K0j = -(i11 * M8j + i12 * M9j), K1j = -(i12 * M8j + i22 * M9j);
+          Pst[s * NA * NA + ei * NA + ej] = Mx + M8i * K0j + M9i * K1j;
+          pst[s * DPSS + psOff] = acc + M8i * kf0 + M9i * kf1;
+          fw[s * DFWS + kOff] = kSel == 0 ? K0j : kSel == 1 ? K1j : kSel == 2 ? kf0 : kf1;
           wv::sync();
+          return okpd;
+        };
+        bool pd = true;
+        {
+          StageEnt eA, eB;
+          load_ent(N - 1, eA);
+          int s = N - 1;
+#pragma clang loop unroll(disable)
+          for (; s >= 1 && pd; s -= 2) {
+            const bool p1 = stage(s, eA, eB);
+            const bool p2 = stage(s - 1, eB, eA);
+            pd = p1 && p2;
+          }
+          if (pd && s == 0) pd = stage(0, eA, eB);
         }
         if (pd) { fact_ok = true; if (dw > 0) dw_last = dw; break; }
         if (first_try) { dw = (dw_last == 0.0) ? DW_FIRST : fmax(DW_MIN, KW_MINUS * dw_last); first_try = false; }
@@ -612,27 +651,42 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       }
       if (!fact_ok) { status = MPCB_ST_NUMERIC; break; }
 
-      // ----- forward roll-out of the step ------------------------------------------------------------------------------
+      // ----- forward roll-out of the step (per-stage numbers contiguous in fw, prefetched one stage ahead) -----------
       double dX[NX] = {0, 0, 0, 0, 0, 0}, dU[NU] = {0, 0};
       {
-        double dx[NA] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma clang loop unroll(disable)
-        for (int s = 0; s < N; ++s) {
-          const double* Ks = Kst + s * 2 * NA;
-          double du0 = kffs[s * 2], du1 = kffs[s * 2 + 1];
+        struct FwEnt { double K[2 * NA], kf0, kf1, a[14], b4, b5, d[NX]; };
+        auto load_fw = [&](int s, FwEnt& f) {
+          const double* q = fw + s * DFWS;
 #pragma unroll
-          for (int r = 0; r < NA; ++r) { du0 += Ks[r] * dx[r]; du1 += Ks[NA + r] * dx[r]; }
-          auto E = [&](int e) { return ent[e * ld + s]; };
-          const double n0 = dx[0] + E(DE_A02) * dx[2] + E(DE_A03) * dx[3] + E(DE_A04) * dx[4] + E(DE_D0);
-          const double n1 = dx[1] + E(DE_A12) * dx[2] + E(DE_A13) * dx[3] + E(DE_A14) * dx[4] + E(DE_D1);
-          const double n2 = dx[2] + T * dx[5] + E(DE_D2);
-          const double n3 = dx[3] + E(DE_A34) * dx[4] + E(DE_A35) * dx[5] + T * du1 + E(DE_D3);
-          const double n4 = E(DE_A43) * dx[3] + E(DE_A44) * dx[4] + E(DE_A45) * dx[5] + E(DE_B4) * du0 + E(DE_D4);
-          const double n5 = E(DE_A53) * dx[3] + E(DE_A54) * dx[4] + E(DE_A55) * dx[5] + E(DE_B5) * du0 + E(DE_D5);
+          for (int r = 0; r < 2 * NA; ++r) f.K[r] = q[r];
+          f.kf0 = q[DFW_KFF]; f.kf1 = q[DFW_KFF + 1];
+#pragma unroll
+          for (int r = 0; r < 14; ++r) f.a[r] = q[DFW_A + r];
+          f.b4 = q[DFW_B]; f.b5 = q[DFW_B + 1];
+#pragma unroll
+          for (int r = 0; r < NX; ++r) f.d[r] = q[DFW_D + r];
+        };
+        double dx[NA] = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto fstage = [&](int s, const FwEnt& f) {
+          MPCB_SCHED_FENCE();
+          const double du0 = f.kf0 + ((f.K[0] * dx[0] + f.K[1] * dx[1]) + (f.K[2] * dx[2] + f.K[3] * dx[3])) +
+                             ((f.K[4] * dx[4] + f.K[5] * dx[5]) + (f.K[6] * dx[6] + f.K[7] * dx[7]));
+          const double du1 = f.kf1 + ((f.K[8] * dx[0] + f.K[9] * dx[1]) + (f.K[10] * dx[2] + f.K[11] * dx[3])) +
+                             ((f.K[12] * dx[4] + f.K[13] * dx[5]) + (f.K[14] * dx[6] + f.K[15] * dx[7]));
+          // a[] = {a02,a03,a04, a12,a13,a14, a34,a35, a43,a44,a45, a53,a54,a55}
+          const double n0 = dx[0] + f.a[0] * dx[2] + f.a[1] * dx[3] + f.a[2] * dx[4] + f.d[0];
+          const double n1 = dx[1] + f.a[3] * dx[2] + f.a[4] * dx[3] + f.a[5] * dx[4] + f.d[1];
+          const double n2 = dx[2] + T * dx[5] + f.d[2];
+          const double n3 = dx[3] + f.a[6] * dx[4] + f.a[7] * dx[5] + T * du1 + f.d[3];
+          const double n4 = f.a[8] * dx[3] + f.a[9] * dx[4] + f.a[10] * dx[5] + f.b4 * du0 + f.d[4];
+          const double n5 = f.a[11] * dx[3] + f.a[12] * dx[4] + f.a[13] * dx[5] + f.b5 * du0 + f.d[5];
           if (k == s) { dU[0] = du0; dU[1] = du1; }
           if (k == s + 1) { dX[0] = n0; dX[1] = n1; dX[2] = n2; dX[3] = n3; dX[4] = n4; dX[5] = n5; }
           dx[0] = n0; dx[1] = n1; dx[2] = n2; dx[3] = n3; dx[4] = n4; dx[5] = n5; dx[6] = du0; dx[7] = du1;
-        }
+        };
+        // one register set only (40 doubles): the dyn kernel is register-bound, a second prefetch set would spill
+#pragma clang loop unroll(disable)
+        for (int s = 0; s < N; ++s) { FwEnt f; load_fw(s, f); fstage(s, f); }
       }
       const double dUp0 = wv::shfl(dU[0], k - 1), dUp1 = wv::shfl(dU[1], k - 1);
       double lamF[NX] = {0, 0, 0, 0, 0, 0};
@@ -641,7 +695,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         const double dxa[NA] = {dX[0], dX[1], dX[2], dX[3], dX[4], dX[5], dUp0, dUp1};
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-          double s = pst[k * NA + i];
+          double s = pst[k * DPSS + i];
 #pragma unroll
           for (int r = 0; r < NA; ++r) s += Pk[i * NA + r] * dxa[r];
           lamF[i] = s;
@@ -772,7 +826,6 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       }
       if (hasu) { U[0] = Ut[0]; U[1] = Ut[1]; }
       sR0 = sR0t; sR1 = sR1t; rR0 = rR0t; rR1 = rR1t; Up0 = upt0; Up1 = upt1;
-      ev = et;
 #pragma unroll
       for (int i = 0; i < NX; ++i) dfc[i] = dft[i];
 #pragma unroll
@@ -788,22 +841,27 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) Xs[i] = X[i];
     if (!(Xs[3] > 1e-3)) Xs[3] = 1e-3;
-    dyn_eval(c, Xs, U, ev);
+    DynEval ev; dyn_eval(c, Xs, U, ev);
     double th, fl, prod;
     eval_lane(Xs, U, sR0, sR1, sO, ev, dfc, rR0, rR1, rO, Up0, Up1, th, fl, prod);
     fval = wv::sum(fl);
   }
 
   // ----- outputs -----------------------------------------------------------------------------------------------------------
+  // `ko` = k behind an optimisation barrier: the LDS addresses of the z staging are re-formed here instead of being kept
+  // live (and spilled) from the identical expressions at kernel start — hipcc 7.2 mis-reloaded such a spilled address in the
+  // dyn<3> build (lanes >= 1 wrote their X rows to zbuf[0..5]).
+  const int ko = wv::opaque(k);
+  const int lo = wv::opaque(lane);      // same for the lane index of the coalesced copy loops
   wv::sync();
-  if (hasu) { zbuf[NU * k] = U[0]; zbuf[NU * k + 1] = U[1]; }
+  if (hasu) { zbuf[NU * ko] = U[0]; zbuf[NU * ko + 1] = U[1]; }
   if (isnode) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) zbuf[NU * N + NX * k + i] = X[i];
+    for (int i = 0; i < NX; ++i) zbuf[NU * N + NX * ko + i] = X[i];
   }
   wv::sync();
-  for (int i = lane; i < nz; i += 64) a.z[(size_t)b * nz + i] = zbuf[i];
-  if (lane == 0) {
+  for (int i = lo; i < nz; i += 64) a.z[(size_t)b * nz + i] = zbuf[i];
+  if (lo == 0) {
     if (a.obj) a.obj[b] = fval;
     if (a.status) a.status[b] = status;
     if (a.iters) a.iters[b] = iters;
@@ -811,15 +869,15 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   }
   if (a.want_mult && a.lam_x) {
     wv::sync();
-    for (int i = lane; i < nz; i += 64) zbuf[i] = 0.0;
+    for (int i = lo; i < nz; i += 64) zbuf[i] = 0.0;
     wv::sync();
-    if (bu0_on) zbuf[NU * k] = -item_y(qU0, iU0) / os;
-    if (bu1_on) zbuf[NU * k + 1] = -item_y(qU1, iU1) / os;
-    if (by_on) zbuf[NU * N + NX * k + 1] = -item_y(qY, iY) / os;
-    if (bvx_on) zbuf[NU * N + NX * k + 3] = -item_y(qVx, iVx) / os;
-    if (bvy_on) zbuf[NU * N + NX * k + 4] = -item_y(qVy, iVy) / os;
+    if (bu0_on) zbuf[NU * ko] = -item_y(qU0, iU0) / os;
+    if (bu1_on) zbuf[NU * ko + 1] = -item_y(qU1, iU1) / os;
+    if (by_on) zbuf[NU * N + NX * ko + 1] = -item_y(qY, iY) / os;
+    if (bvx_on) zbuf[NU * N + NX * ko + 3] = -item_y(qVx, iVx) / os;
+    if (bvy_on) zbuf[NU * N + NX * ko + 4] = -item_y(qVy, iVy) / os;
     wv::sync();
-    for (int i = lane; i < nz; i += 64) a.lam_x[(size_t)b * nz + i] = zbuf[i];
+    for (int i = lo; i < nz; i += 64) a.lam_x[(size_t)b * nz + i] = zbuf[i];
   }
   if (a.want_mult && a.lam_g) {
     // g order: [X_0 - P](6); then per stage i: dynamics(6) and, for i > 0, the rate rows (interleaved, dyn.py:226-231)
@@ -837,7 +895,12 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       for (int i = 0; i < NX; ++i) out[dyn_row(k) + i] = -lam[i] / os;
     }
     if (k == 0) {
-      DynJac J; dyn_jac(c, X, ev, J);
+      double Xs[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) Xs[i] = X[i];
+      if (!(Xs[3] > 1e-3)) Xs[3] = 1e-3;
+      DynEval ev; dyn_eval(c, Xs, U, ev);
+      DynJac J; dyn_jac(c, Xs, ev, J);
       const double At[NX] = {ln[0], ln[1], J.a02 * ln[0] + J.a12 * ln[1] + ln[2],
                              J.a03 * ln[0] + J.a13 * ln[1] + ln[3] + J.a43 * ln[4] + J.a53 * ln[5],
                              J.a04 * ln[0] + J.a14 * ln[1] + J.a34 * ln[3] + J.a44 * ln[4] + J.a54 * ln[5],

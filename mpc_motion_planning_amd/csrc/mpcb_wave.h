@@ -70,6 +70,8 @@ template <int NS, int NM> MPCB_DEV void reduce(double* s, double* m) {
   MPCB_STEP(__shfl_xor(v, 32, 64))
 #undef MPCB_STEP
 }
+// the same value, but opaque to the optimiser (breaks common-subexpression reuse across the kernel)
+MPCB_DEV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 // a wave-uniform double moved to scalar registers
 MPCB_DEV double uni(double v) {
   int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
@@ -131,6 +133,7 @@ template <int NS, int NM> inline void reduce(double* s, double* m) {
   for (int i = 0; i < NS; ++i) s[i] = sum(s[i]);
   for (int i = 0; i < NM; ++i) m[i] = max(m[i]);
 }
+inline int opaque(int v) { return v; }
 inline double uni(double v) { return v; }
 inline double rcp(double x) { return 1.0 / x; }
 }  // namespace wv

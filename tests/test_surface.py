@@ -68,3 +68,23 @@ def test_sharding_bounds():
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(W - 1))
             sizes = [hi - lo for lo, hi in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_result_dict_constraint_values_follow_reference_row_order():
+    """res['g'] is computed on the host in the reference's g order; check it against the independent restatement."""
+    from oracle import kkt_check
+    from mpc_motion_planning_amd._mpc_base import nlp_constraints
+    from mpc_motion_planning_amd import _abi
+    m = MPC_CBF_optimize_kin.MPC_optimize()
+    rng = np.random.default_rng(1)
+    obs = np.array([[50, 3.5, 0, 8, 4.8, 1.8], [70, 0.2, 0, 5, 4.2, 1.7]])
+    cfg = m._make_cfg(2)
+    z = rng.normal(size=184) * 0.1; z[60::4] += np.linspace(0, 40, 31); z[63::4] += 15
+    x0 = np.array([0.3, 2.9, 0.01, 14.0])
+    g = nlp_constraints(cfg, z, x0, obs[None], _abi.OBSIN_STATIC)
+    ref = kkt_check.KinNlp(30, 0.1, x0, [400, 3.5, 0, 30], obs).g(z)
+    assert g.shape == ref.shape == (124 + 29 + 60,) and np.abs(g - ref).max() <= 1e-12
+    cfg.obs_mode = _abi.OBS_DCBF                                   # gamma = 1: row i is h_i(X_{i+1})
+    g = nlp_constraints(cfg, z, x0, obs[None], _abi.OBSIN_STATIC)
+    ref = kkt_check.KinNlp(30, 0.1, x0, [400, 3.5, 0, 30], obs, obs_mode="dcbf", gamma=1.0).g(z)
+    assert np.abs(g - ref).max() <= 1e-12
