@@ -413,6 +413,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       // tyre forces and trig at the iterate are recomputed here rather than kept across the line search (13 doubles/lane)
       DynEval ev; dyn_eval(c, X, U, ev);
       DynJac J; dyn_jac(c, X, ev, J);
+      recips();
       double ln[NX];
 #pragma unroll
       for (int i = 0; i < NX; ++i) ln[i] = wv::shfl(lam[i], k + 1);
@@ -587,7 +588,8 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           e.startU = ent[sStartU + s]; e.hU = ent[sHU + s]; e.startUU = ent[sStartUU + s];
           e.b4 = ent[DE_B4 * ld + s]; e.b5 = ent[DE_B5 * ld + s];
         };
-        auto stage = [&](int s, const StageEnt& e, StageEnt& nxt) -> bool {
+        auto stage = [&](int s) -> bool {
+          StageEnt e; load_ent(s, e);
           const double* Pn = Pst + (s + 1) * NA * NA + ei * NA;
           double Pr[NA];
 #pragma unroll
@@ -600,7 +602,6 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           const double wu = (ej & 1) ? fma(T, Pr[3], Pr[7]) : fma(e.b4, Pr[4], fma(e.b5, Pr[5], Pr[6]));
           Wl[ej * NA + ei] = w;
           WuL[wuOff] = wu;
-          load_ent(s > 0 ? s - 1 : 0, nxt);
           wv::sync();
           double Wc[NA], Wuc[NA];
 #pragma unroll
@@ -632,18 +633,8 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           return okpd;
         };
         bool pd = true;
-        {
-          StageEnt eA, eB;
-          load_ent(N - 1, eA);
-          int s = N - 1;
 #pragma clang loop unroll(disable)
-          for (; s >= 1 && pd; s -= 2) {
-            const bool p1 = stage(s, eA, eB);
-            const bool p2 = stage(s - 1, eB, eA);
-            pd = p1 && p2;
-          }
-          if (pd && s == 0) pd = stage(0, eA, eB);
-        }
+        for (int s = N - 1; s >= 0 && pd; --s) pd = stage(s);       // one register set for the stage tables: the dyn kernel is register-bound
         if (pd) { fact_ok = true; if (dw > 0) dw_last = dw; break; }
         if (first_try) { dw = (dw_last == 0.0) ? DW_FIRST : fmax(DW_MIN, KW_MINUS * dw_last); first_try = false; }
         else dw *= (dw_last == 0.0) ? KW_PLUS_FIRST : KW_PLUS;
@@ -706,6 +697,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
 #pragma unroll
       for (int j = 0; j < NOBS; ++j) dsO[j] = ro_on[j] ? gO0[j] * dX[0] + gO1[j] * dX[1] + rO[j] : 0.0;
 
+      recips();                    // (re)computed per phase instead of being kept live across the sweeps: register pressure
       double a_pr, a_du, dphi;
       {
         double rpr = 0, rdu = 0, d = 0;
@@ -799,6 +791,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         wv::sync();
       }
 
+      recips();
       auto upd = [&](const Bnd& q, Item& it, double ds, double snew) {
         double dvL, dvU; item_dv(q, it, ds, mu, dvL, dvU);
         it.vL += a_du * dvL; it.vU += a_du * dvU;
