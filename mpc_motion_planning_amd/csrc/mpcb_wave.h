@@ -17,7 +17,19 @@
 
 namespace wv {
 MPCB_DEV int lane() { return (int)threadIdx.x; }
+// One wavefront per workgroup: the LDS unit executes the DS instructions of a wave in issue order, so a store by one
+// lane followed by a load by another lane needs NO s_waitcnt and no s_barrier in between — only the compiler has to keep
+// the program order.  Wavefront-scope fences + wave_barrier do exactly that and emit no instruction; the loads that
+// follow are then waited for individually (counted lgkmcnt), so independent DS traffic stays in flight across a "sync".
+#ifdef MPCB_SYNC_BLOCK
 MPCB_DEV void sync() { __syncthreads(); }
+#else
+MPCB_DEV void sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#endif
 MPCB_DEV double shfl(double v, int src) { return __shfl(v, src, 64); }
 MPCB_DEV int shfl(int v, int src) { return __shfl(v, src, 64); }
 // value of lane `src` (wave-uniform index) in every lane
