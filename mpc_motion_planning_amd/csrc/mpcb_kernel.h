@@ -638,7 +638,6 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           const double w = fma(Pr[4], e.abj[4], fma(Pr[2], e.abj[2], fma(Pr[0], e.abj[0], w0))) +
                            fma(Pr[5], e.abj[5], fma(Pr[3], e.abj[3], Pr[1] * e.abj[1]));
           Wl[wOff] = w;
-          load_ent(s > 0 ? s - 1 : 0, nxt);                       // prefetch for the next stage, off the critical path
           wv::sync();
           double Wc[NA];
 #pragma unroll
@@ -655,6 +654,12 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           // rows 6,7 of M at column j and at column i (M is symmetric up to rounding)
           const double M6j = wv::shfl(Mx, NA * 8 + ej), M7j = wv::shfl(Mx, (NA + 1) * 8 + ej);
           const double M6i = wv::shfl(Mx, NA * 8 + ei), M7i = wv::shfl(Mx, (NA + 1) * 8 + ei);
+          // prefetch for the next stage behind the exchanges of this one: the DS queue is in order, so these 14 reads must
+          // not sit in front of the W / M traffic of the recursion (index -1 after stage 0 reads the tail of the filter
+          // region: in bounds, never used)
+          MPCB_SCHED_FENCE();
+          load_ent(s - 1, nxt);
+          MPCB_SCHED_FENCE();
           const double det = m11 * m22 - m12 * m12;
           const bool okpd = (m11 > 0) && (det > 1e-14 * m11 * m22) && isfinite(det);   // wave-uniform
           const double idet = wv::rcp(det);
