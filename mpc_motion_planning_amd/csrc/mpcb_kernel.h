@@ -67,13 +67,15 @@ enum KinEnt {
 };
 
 // LDS layout (doubles).  ld = (N+1)|1: odd leading dimension of the [entry][node] tables.
-//   Pst [N+1][PST]   P_k (6x6, row-major) + 4 pad slots that absorb the stores of lanes without a P entry
-//   pst [N+1][8]     p_k (6), slot 6 is a permanent 0.0 (base value of the W accumulation in non-affine lanes), slot 7 pad
+//   Pst [N+1][PST]   P_k (6x6, row-major, slots 0..35), p_k (slots 36..41), a permanent 0.0 (slot 42: unit term of lanes
+//                    without one), pad slot 43 (p stores of non-affine lanes), pad slots 44..47 (P stores of lanes without a
+//                    P entry)
 //   fw  [N+1][FWS]   everything the forward roll-out reads for stage k, contiguous: K (2x6), kff (2), a02 a03 a12 a13 a23 b20,
 //                    d0..d3, then 4 pad slots for the K stores of lanes without a K entry
-constexpr int PST = 40, PSS = 8, FWS = 28, FW_KFF = 12, FW_A = 14, FW_D = 20, FW_PAD = 24, WSZ = 64;
+constexpr int PST = 48, PS_P = 36, PS_ZERO = 42, PS_PADP = 43, PS_PAD = 44;
+constexpr int FWS = 28, FW_KFF = 12, FW_A = 14, FW_D = 20, FW_PAD = 24, WSZ = 72, W_ZERO = 64;
 struct Layout {
-  int ld, ent, Pst, pst, fw, W, filt, zbuf, total;
+  int ld, ent, Pst, fw, W, filt, zbuf, total;
 };
 MPCB_HD Layout layout_kin(int N, int nz) {
   Layout L;
@@ -81,9 +83,8 @@ MPCB_HD Layout layout_kin(int N, int nz) {
   L.ld = N1 | 1;
   int o = 0;
   L.Pst = o; o += N1 * PST;          // first: 16-byte aligned rows for wide LDS reads
-  L.pst = o; o += N1 * PSS;
   L.fw = o; o += N1 * FWS;
-  L.W = o; o += WSZ;                 // W^T (8 columns x 6) + 16 pad slots
+  L.W = o; o += WSZ;                 // W^T (8 columns x 6) + 16 pad slots + a permanent 0.0 (W_ZERO)
   L.filt = o; o += 2 * FILTER_MAX;
   L.ent = o; o += KIN_NENT * L.ld;
   L.zbuf = L.Pst;                    // staging of z rows aliases the Riccati storage (used before / after the loop)
@@ -411,30 +412,40 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   // arithmetic.  The lanes of that column therefore carry the AFFINE part of the recursion through the same instruction
   // stream: their "[A B] column" is the defect d, their accumulation starts from p+ (resp. g), so W(:,4) := q and their
   // M accumulator := m.  No lane computes q or m redundantly.
+  // [A B] = [I + sparse | 0 | sparse; 0 | 0 | I]: rows 4,5 (U_prev+ = U) hold a single 1, so every column / row of the
+  // products needs the 4 coefficients of the state rows plus at most ONE unit term read straight from P+ (resp. W):
+  //   W(i,j) = sum_{r<4} P+(i,r) AB(r,j) + [j=6] P+(i,4) + [j=7] P+(i,5)          (+ p+_i in the affine column)
+  //   M(i,j) = H(i,j) + sum_{r<4} AB(r,i) W(r,j) + [i=6] W(4,j) + [i=7] W(5,j)
   const bool aff = (ej == 4);
-  int sABj[NA], sABi[NA];
+  int sCW[NX], sCM[NX];
 #pragma unroll
-  for (int r = 0; r < NA; ++r) {
-    sABj[r] = (aff ? (r < NX ? E_D0 + r : E_ZERO) : slotAB(r, ej)) * ld;
-    sABi[r] = slotAB(r, ei) * ld;
+  for (int r = 0; r < NX; ++r) {
+    sCW[r] = (aff ? E_D0 + r : slotAB(r, ej)) * ld;
+    sCM[r] = slotAB(r, ei) * ld;
   }
   const int sHij = slotH(ei, ej) * ld, sGi = (E_G0 + ei) * ld;
   const int sStart = aff ? sGi : sHij;         // start value of the M accumulation: g_i in the affine lanes, H_ij elsewhere
   const int eiA = ei < NA ? ei : 0;            // clamped row for lanes of the control rows (their W is unused)
-  const int pvOff = aff ? eiA : 6;             // base of the W accumulation: p+_i in the affine lanes, the permanent 0 elsewhere
+  // unit term of W inside the Pst row of stage s+1: p+_i (affine lanes), P+(i,4) / P+(i,5) (control columns), else the 0.0 slot
+  const int uWOff = ei >= NA ? PS_ZERO : aff ? PS_P + ei : ej == 6 ? ei * NA + 4 : ej == 7 ? ei * NA + 5 : PS_ZERO;
+  // unit term of M inside W^T: W(4,j) / W(5,j) in the control rows, else the 0.0 slot
+  const int uMOff = ei == 6 ? ej * NA + 4 : ei == 7 ? ej * NA + 5 : W_ZERO;
   // store targets; lanes without an entry write into pad slots, so that the sweep has no divergent branches
   const int wOff = ei < NA ? ej * NA + ei : NW * NA + (lane & 15);
-  const int pOff = (ei < NA && ej < NA) ? ei * NA + ej : NA * NA + (lane & 3);
-  const int psOff = (aff && ei < NA) ? ei : 7;
-  const int kOff = (ej < NA && ei == 0) ? ej : (ej < NA && ei == 1) ? NA + ej : (lane == 62) ? FW_KFF : (lane == 63) ? FW_KFF + 1 : FW_PAD + (lane & 3);
-  const int kSel = (ei == 1) ? 1 : (lane == 62) ? 2 : (lane == 63) ? 3 : 0;   // which of K0j, K1j, kf0, kf1 this lane stores
+  const int pOff = (ei < NA && ej < NA) ? ei * NA + ej : PS_PAD + (lane & 3);
+  const int psOff = (aff && ei < NA) ? PS_P + ei : PS_PADP;
+  // gains: lanes (0,j) store K0j, lanes (1,j) store K1j (j < 6); lanes 62 / 63 store the feed-forward terms
+  const int kOff = (ej < NA && ei == 0) ? ej : (ej < NA && ei == 1) ? NA + ej : FW_PAD + (lane & 1);
+  const int kfOff = (lane == 62) ? FW_KFF : (lane == 63) ? FW_KFF + 1 : FW_PAD + 2 + (lane & 1);
+  const bool kRow1 = (ei == 1), kfLane1 = (lane == 63);
 
   // constant rows of the entry table
   if (isnode) { ent[E_ZERO * ld + k] = 0.0; ent[E_ONE * ld + k] = 1.0; ent[E_T * ld + k] = T; }
-  // (pst slot 6 = 0.0 is written after the z0 staging below has finished with the aliased region)
+  // (Pst slot PS_ZERO = 0.0 is written after the z0 staging below has finished with the aliased region)
 
-  double* Pst = lds + L.Pst; double* pst = lds + L.pst; double* fw = lds + L.fw;
+  double* Pst = lds + L.Pst; double* fw = lds + L.fw;
   double* Wl = lds + L.W; double* filt = lds + L.filt;
+  if (lane == 0) Wl[W_ZERO] = 0.0;
   int nfilt = 0;
   double theta_max = 0, theta_min = 0;
   double dw_last = 0.0;
@@ -596,7 +607,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           fk[FW_A + 3] = hasu ? a13 : 0.0; fk[FW_A + 4] = hasu ? a23 : 0.0; fk[FW_A + 5] = hasu ? b20 : 0.0;
 #pragma unroll
           for (int i = 0; i < NX; ++i) fk[FW_D + i] = dfc[i];
-          pst[k * PSS + 6] = 0.0;
+          Pst[k * PST + PS_ZERO] = 0.0;
           ent[E_HXY * ld + k] = hxy; ent[E_HPV * ld + k] = hpv; ent[E_HVD * ld + k] = hvd;
           ent[E_H44 * ld + k] = h44; ent[E_H55 * ld + k] = h55; ent[E_H46 * ld + k] = h46; ent[E_H57 * ld + k] = h57;
         }
@@ -615,41 +626,39 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         wv::sync();
         // terminal: P_N = H_N (state block), p_N = g_N
         if (ei < NA && ej < NA) Pst[N * PST + ei * NA + ej] = ent[sHij + N];
-        if (ei < NA && ej == 0) pst[N * PSS + ei] = ent[sGi + N];
+        if (ei < NA && ej == 0) Pst[N * PST + PS_P + ei] = ent[sGi + N];
         wv::sync();
         // Stage entries (18 table values per lane) do not depend on the recursion: they are prefetched one stage ahead
         // into a second register set (ping-pong, no copies) so that only the P+ row and the W exchange sit on the
         // critical path.  MPCB_SCHED_FENCE keeps the compiler from sinking the batched loads next to their uses.
-        struct StageEnt { double abj[NA], abi[NA], start, hmat; };
+        struct StageEnt { double cw[NX], cm[NX], start, hmat; };
         auto load_ent = [&](int s, StageEnt& e) {
 #pragma unroll
-          for (int r = 0; r < NA; ++r) { e.abj[r] = ent[sABj[r] + s]; e.abi[r] = ent[sABi[r] + s]; }
+          for (int r = 0; r < NX; ++r) { e.cw[r] = ent[sCW[r] + s]; e.cm[r] = ent[sCM[r] + s]; }
           e.start = ent[sStart + s]; e.hmat = ent[sHij + s];
         };
         auto stage = [&](int s, const StageEnt& e, StageEnt& nxt) -> bool {
           // W = P+ [A B | d] (+ p+ in the affine column)      lane (i,j): row i of P+, column j
-          const double* Pn = Pst + (s + 1) * PST + eiA * NA;
-          double Pr[NA];
+          const double* Pn = Pst + (s + 1) * PST;
+          double Pr[NX];
 #pragma unroll
-          for (int r = 0; r < NA; ++r) Pr[r] = Pn[r];
-          const double w0 = pst[(s + 1) * PSS + pvOff];
+          for (int r = 0; r < NX; ++r) Pr[r] = Pn[eiA * NA + r];
+          const double w0 = Pn[uWOff];
           MPCB_SCHED_FENCE();
           // two partial sums: halves the dependent FMA chain on the critical path of the recursion
-          const double w = fma(Pr[4], e.abj[4], fma(Pr[2], e.abj[2], fma(Pr[0], e.abj[0], w0))) +
-                           fma(Pr[5], e.abj[5], fma(Pr[3], e.abj[3], Pr[1] * e.abj[1]));
+          const double w = fma(Pr[2], e.cw[2], fma(Pr[0], e.cw[0], w0)) + fma(Pr[3], e.cw[3], Pr[1] * e.cw[1]);
           Wl[wOff] = w;
           wv::sync();
-          double Wc[NA];
+          double Wc[NX];
 #pragma unroll
-          for (int r = 0; r < NA; ++r) Wc[r] = Wl[ej * NA + r];
+          for (int r = 0; r < NX; ++r) Wc[r] = Wl[ej * NA + r];
+          const double m0 = Wl[uMOff];
           MPCB_SCHED_FENCE();
           // M = H + [A B]^T W; in the affine lanes the same sum is m = g + [A B]^T q
-          const double acc = fma(e.abi[4], Wc[4], fma(e.abi[2], Wc[2], fma(e.abi[0], Wc[0], e.start))) +
-                             fma(e.abi[5], Wc[5], fma(e.abi[3], Wc[3], e.abi[1] * Wc[1]));
+          const double acc = fma(e.cm[2], Wc[2], fma(e.cm[0], Wc[0], e.start)) + fma(e.cm[3], Wc[3], fma(e.cm[1], Wc[1], m0));
           const double Mx = aff ? e.hmat : acc;                   // matrix value of this lane (column 4: H itself)
           // control block Muu (lanes (6,6),(6,7),(7,6),(7,7)) and m_u (affine lanes (6,4),(7,4)) to every lane
-          const double m11 = wv::bcast(Mx, NA * 8 + NA), m12 = 0.5 * (wv::bcast(Mx, NA * 8 + NA + 1) + wv::bcast(Mx, (NA + 1) * 8 + NA));
-          const double m22 = wv::bcast(Mx, (NA + 1) * 8 + NA + 1);
+          const double m11 = wv::bcast(Mx, NA * 8 + NA), m12 = wv::bcast(Mx, NA * 8 + NA + 1), m22 = wv::bcast(Mx, (NA + 1) * 8 + NA + 1);
           const double mu6 = wv::bcast(acc, NA * 8 + 4), mu7 = wv::bcast(acc, (NA + 1) * 8 + 4);
           // rows 6,7 of M at column j and at column i (M is symmetric up to rounding)
           const double M6j = wv::shfl(Mx, NA * 8 + ej), M7j = wv::shfl(Mx, (NA + 1) * 8 + ej);
@@ -660,15 +669,16 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           MPCB_SCHED_FENCE();
           load_ent(s - 1, nxt);
           MPCB_SCHED_FENCE();
-          const double det = m11 * m22 - m12 * m12;
-          const bool okpd = (m11 > 0) && (det > 1e-14 * m11 * m22) && isfinite(det);   // wave-uniform
+          const double det = m11 * m22 - m12 * m12, dmar = det - 1e-14 * m11 * m22;
+          const bool okpd = (m11 > 0) & (dmar > 0) & (dmar < 1e300);                    // wave-uniform; false for NaN / inf
           const double idet = wv::rcp(det);
           const double i11 = m22 * idet, i12 = -m12 * idet, i22 = m11 * idet;
           const double kf0 = -(i11 * mu6 + i12 * mu7), kf1 = -(i12 * mu6 + i22 * mu7);
           const double K0j = -(i11 * M6j + i12 * M7j), K1j = -(i12 * M6j + i22 * M7j);
           Pst[s * PST + pOff] = Mx + M6i * K0j + M7i * K1j;                 // P_s (lanes i,j < 6), pad elsewhere
-          pst[s * PSS + psOff] = acc + M6i * kf0 + M7i * kf1;               // p_s (affine lanes), pad slot 7 elsewhere
-          fw[s * FWS + kOff] = kSel == 0 ? K0j : kSel == 1 ? K1j : kSel == 2 ? kf0 : kf1;
+          Pst[s * PST + psOff] = acc + M6i * kf0 + M7i * kf1;               // p_s (affine lanes), pad slot elsewhere
+          fw[s * FWS + kOff] = kRow1 ? K1j : K0j;
+          fw[s * FWS + kfOff] = kfLane1 ? kf1 : kf0;
           wv::sync();
           return okpd;                                   // a failed stage leaves garbage behind; the sweep is repeated with a larger delta_w
         };
@@ -737,7 +747,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         const double dxa[NA] = {dX[0], dX[1], dX[2], dX[3], dUp0, dUp1};
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-          double s = pst[k * PSS + i];
+          double s = Pk[PS_P + i];
 #pragma unroll
           for (int r = 0; r < NA; ++r) s += Pk[i * NA + r] * dxa[r];
           lamF[i] = s;
