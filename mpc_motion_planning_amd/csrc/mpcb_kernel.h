@@ -687,13 +687,23 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           StageEnt eA, eB;
           load_ent(N - 1, eA);
           int s = N - 1;
+          // four stages per trip: the per-lane table addresses (10 registers) advance once per trip, the stages in between
+          // use immediate offsets
 #pragma clang loop unroll(disable)
-          for (; s >= 1 && pd; s -= 2) {
+          for (; s >= 3 && pd; s -= 4) {
             const bool p1 = stage(s, eA, eB);
             const bool p2 = stage(s - 1, eB, eA);
-            pd = p1 && p2;
+            const bool p3 = stage(s - 2, eA, eB);
+            const bool p4 = stage(s - 3, eB, eA);
+            pd = p1 & p2 & p3 & p4;
           }
-          if (pd && s == 0) pd = stage(0, eA, eB);
+          if (pd && s >= 0) {
+            pd = stage(s, eA, eB);
+            if (pd && s >= 1) {
+              pd = stage(s - 1, eB, eA);
+              if (pd && s >= 2) pd = stage(s - 2, eA, eB);
+            }
+          }
         }
         if (pd) { fact_ok = true; if (dw > 0) dw_last = dw; break; }
         if (first_try) { dw = (dw_last == 0.0) ? DW_FIRST : fmax(DW_MIN, KW_MINUS * dw_last); first_try = false; }
