@@ -383,8 +383,10 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   const int pvOff = aff ? ei : 8;
   const int wuOff = ej < 2 ? ej * NA + ei : 16 + (lane & 15);
   const int psOff = aff ? ei : 9;
-  const int kOff = (ei == 0) ? ej : (ei == 1) ? NA + ej : (lane == 62) ? DFW_KFF : (lane == 63) ? DFW_KFF + 1 : DFW_PAD + (lane & 3);
-  const int kSel = (ei == 1) ? 1 : (lane == 62) ? 2 : (lane == 63) ? 3 : 0;
+  // gains: lanes (0,j) store K0j, lanes (1,j) store K1j; lanes 62 / 63 store the feed-forward terms; pad slots elsewhere
+  const int kOff = (ei == 0) ? ej : (ei == 1) ? NA + ej : DFW_PAD + (lane & 1);
+  const int kfOff = (lane == 62) ? DFW_KFF : (lane == 63) ? DFW_KFF + 1 : DFW_PAD + 2 + (lane & 1);
+  const bool kRow1 = (ei == 1), kfLane1 = (lane == 63);
   if (isnode) { ent[DE_ZERO * ld + k] = 0.0; ent[DE_ONE * ld + k] = 1.0; ent[DE_T * ld + k] = T; }
 
   double* Pst = lds + L.Pst; double* pst = lds + L.pst; double* fw = lds + L.fw;
@@ -616,19 +618,20 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           const double muu = e.startUU + (cU ? fma(T, Wuc[3], Wuc[7]) : fma(e.b4, Wuc[4], fma(e.b5, Wuc[5], Wuc[6])));
           const double Mx = aff ? e.hmat : acc;
           const double MxU = aff ? e.hU : mux;
-          const double m11 = wv::bcast(muu, 48), m12 = 0.5 * (wv::bcast(muu, 49) + wv::bcast(muu, 56)), m22 = wv::bcast(muu, 57);
+          const double m11 = wv::bcast(muu, 48), m12 = wv::bcast(muu, 49), m22 = wv::bcast(muu, 57);
           const double mu8 = wv::bcast(mux, 54), mu9 = wv::bcast(mux, 62);
           const double M8j = wv::shfl(MxU, 48 + ej), M9j = wv::shfl(MxU, 56 + ej);
           const double M8i = wv::shfl(MxU, 48 + ei), M9i = wv::shfl(MxU, 56 + ei);
-          const double det = m11 * m22 - m12 * m12;
-          const bool okpd = (m11 > 0) && (det > 1e-14 * m11 * m22) && isfinite(det);
+          const double det = m11 * m22 - m12 * m12, dmar = det - 1e-14 * m11 * m22;
+          const bool okpd = (m11 > 0) & (dmar > 0) & (dmar < 1e300);                    // wave-uniform; false for NaN / inf
           const double idet = wv::rcp(det);
           const double i11 = m22 * idet, i12 = -m12 * idet, i22 = m11 * idet;
           const double kf0 = -(i11 * mu8 + i12 * mu9), kf1 = -(i12 * mu8 + i22 * mu9);
           const double K0j = -(i11 * M8j + i12 * M9j), K1j = -(i12 * M8j + i22 * M9j);
           Pst[s * NA * NA + ei * NA + ej] = Mx + M8i * K0j + M9i * K1j;
           pst[s * DPSS + psOff] = acc + M8i * kf0 + M9i * kf1;
-          fw[s * DFWS + kOff] = kSel == 0 ? K0j : kSel == 1 ? K1j : kSel == 2 ? kf0 : kf1;
+          fw[s * DFWS + kOff] = kRow1 ? K1j : K0j;
+          fw[s * DFWS + kfOff] = kfLane1 ? kf1 : kf0;
           wv::sync();
           return okpd;
         };
