@@ -645,8 +645,9 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           for (int r = 0; r < NX; ++r) Pr[r] = Pn[eiA * NA + r];
           const double w0 = Pn[uWOff];
           MPCB_SCHED_FENCE();
-          // two partial sums: halves the dependent FMA chain on the critical path of the recursion
-          const double w = fma(Pr[2], e.cw[2], fma(Pr[0], e.cw[0], w0)) + fma(Pr[3], e.cw[3], Pr[1] * e.cw[1]);
+          // one FMA chain: a dependent v_fma_f64 issues after 5.6 ticks against 4.5 for an independent one (tools/ubench/
+          // fma_latency.hip), so splitting the chain only adds the instruction that joins the halves
+          const double w = fma(Pr[3], e.cw[3], fma(Pr[2], e.cw[2], fma(Pr[1], e.cw[1], fma(Pr[0], e.cw[0], w0))));
           Wl[wOff] = w;
           wv::sync();
           double Wc[NX];
@@ -655,7 +656,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           const double m0 = Wl[uMOff];
           MPCB_SCHED_FENCE();
           // M = H + [A B]^T W; in the affine lanes the same sum is m = g + [A B]^T q
-          const double acc = fma(e.cm[2], Wc[2], fma(e.cm[0], Wc[0], e.start)) + fma(e.cm[3], Wc[3], fma(e.cm[1], Wc[1], m0));
+          const double acc = fma(e.cm[3], Wc[3], fma(e.cm[2], Wc[2], fma(e.cm[1], Wc[1], fma(e.cm[0], Wc[0], e.start)))) + m0;
           const double Mx = aff ? e.hmat : acc;                   // matrix value of this lane (column 4: H itself)
           // control block Muu (lanes (6,6),(6,7),(7,6),(7,7)) and m_u (affine lanes (6,4),(7,4)) to every lane
           const double m11 = wv::bcast(Mx, NA * 8 + NA), m12 = wv::bcast(Mx, NA * 8 + NA + 1), m22 = wv::bcast(Mx, (NA + 1) * 8 + NA + 1);
@@ -730,12 +731,12 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         auto fstage = [&](int s, const FwEnt& f, FwEnt& nxt) {
           load_fw(s + 1 < N ? s + 1 : s, nxt);
           MPCB_SCHED_FENCE();
-          const double du0 = f.kf0 + (f.K[0] * dx0 + f.K[1] * dx1) + (f.K[2] * dx2 + f.K[3] * dx3) + (f.K[4] * dx4 + f.K[5] * dx5);
-          const double du1 = f.kf1 + (f.K[6] * dx0 + f.K[7] * dx1) + (f.K[8] * dx2 + f.K[9] * dx3) + (f.K[10] * dx4 + f.K[11] * dx5);
-          const double n0 = dx0 + f.a02 * dx2 + f.a03 * dx3 + f.d0;
-          const double n1 = dx1 + f.a12 * dx2 + f.a13 * dx3 + f.d1;
-          const double n2 = dx2 + f.a23 * dx3 + f.b20 * du0 + f.d2;
-          const double n3 = dx3 + T * du1 + f.d3;
+          const double du0 = fma(f.K[5], dx5, fma(f.K[4], dx4, fma(f.K[3], dx3, fma(f.K[2], dx2, fma(f.K[1], dx1, fma(f.K[0], dx0, f.kf0))))));
+          const double du1 = fma(f.K[11], dx5, fma(f.K[10], dx4, fma(f.K[9], dx3, fma(f.K[8], dx2, fma(f.K[7], dx1, fma(f.K[6], dx0, f.kf1))))));
+          const double n0 = fma(f.a03, dx3, fma(f.a02, dx2, dx0 + f.d0));
+          const double n1 = fma(f.a13, dx3, fma(f.a12, dx2, dx1 + f.d1));
+          const double n2 = fma(f.b20, du0, fma(f.a23, dx3, dx2 + f.d2));
+          const double n3 = fma(T, du1, dx3 + f.d3);
           if (k == s) { dU[0] = du0; dU[1] = du1; }
           if (k == s + 1) { dX[0] = n0; dX[1] = n1; dX[2] = n2; dX[3] = n3; }
           dx0 = n0; dx1 = n1; dx2 = n2; dx3 = n3; dx4 = du0; dx5 = du1;

@@ -1,0 +1,27 @@
+"""Diagnostic: per-phase cycle counts of one interior-point iteration (s_memtime stamps inside the kernel).
+Builds a second library with -DMPCB_STAMPS (never shipped) and runs the shipped C2 scene through mpcb_solve_trace:
+    python tools/phase_stamps.py [kin|dyn]
+Columns: condense+KKT, Riccati sweep, forward+costates+ratios, line search (s_memtime ticks)."""
+import os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+out = os.path.join(ROOT, "mpc_motion_planning_amd", "lib", "libmpcbatch_stamps.so")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-fno-gpu-rdc",
+                       "-DMPCB_STAMPS", "-o", out, os.path.join(ROOT, "mpc_motion_planning_amd", "csrc", "mpcb_api.hip")],
+                      stderr=subprocess.DEVNULL)
+import mpc_motion_planning_amd._lib as _lib
+_lib.LIB_PATH = out
+from mpc_motion_planning_amd import scenes
+from mpc_motion_planning_amd.solver import BatchSolver, default_config
+
+cfg = default_config(N=30, T=0.1, n_obs=1)
+bs = BatchSolver(cfg)
+x0, xs, obs = scenes.SHIPPED_X0, scenes.SHIPPED_XS, scenes.SHIPPED_OBS.reshape(1, 1, 6)
+r = bs.solve_trace(x0, xs, obs)
+tr = r["trace"][: int(r["iters"])]
+c = tr[:, 4:8]
+print("iters", int(r["iters"]), "status", int(r["status"]))
+print("mean cycles/iter: condense+KKT %.0f  Riccati %.0f  forward+costates+ratios %.0f  line search %.0f  total %.0f"
+      % (*c.mean(0), c.sum(1).mean()))
+os.remove(out)
