@@ -32,6 +32,20 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-le
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (spec)
 
 
+def measured_traffic(workload):
+    """HBM bytes per launch of this workload from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate passes, KiB units,
+    2x correction on FETCH_SIZE as MI355X_MICROARCH.md prescribes), recorded by tools/profile_round.sh in profiles/traffic.json.
+    bench.py cannot collect PMC counters on itself, so this is the committed measurement of the same command; None if absent."""
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+    try:
+        t = json.load(open(p))
+        if t.get("workload") == workload:
+            return float(t["bytes_per_launch"]), "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
 def algorithmic_bytes_per_solve(nx, nz, n_obs_values):
     # SURVEY.md §8(d): 8*(2*nx + nz_in + obs_in + nz_out) + 16   (status i32 + iters i32 + obj f64)
     return 8 * (2 * nx + nz + n_obs_values + nz) + 16
@@ -192,6 +206,7 @@ def main():
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
         it_ok = iters[status == 0]
         flops = (147e3 if cfg.model == _abi.MODEL_DYN else 56e3) * float(iters.sum())   # ~56 kflop (kin N=30) / ~147 kflop (dyn N=40) per iteration
+        traffic, traffic_src = measured_traffic(workload)
         out = {
             "metric": "mpc_solves_per_sec", "value": solved_all * args.steps / dt_max, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
@@ -200,7 +215,7 @@ def main():
                        "iters_mean_solved": float(it_ok.mean()) if len(it_ok) else None, "iters_max": int(iters.max()),
                        "tol": cfg.tol, "collective": "rccl all_gather of z per step" if use_dist else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "mpcb_kernel_%s<%d>" % ("dyn" if cfg.model == _abi.MODEL_DYN else "kin", 1 if cfg.n_obs <= 1 else 3), "kernel_ms_avg": kernel_ms,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "mpcb_kernel_%s<%d>" % ("dyn" if cfg.model == _abi.MODEL_DYN else "kin", 1 if cfg.n_obs <= 1 else 3), "kernel_ms_avg": kernel_ms,
                          "algorithmic_bytes_per_launch": abytes,
                          "note": "compulsory I/O is 3072 B/solve; the solve is LDS-resident, bound by FP64 VALU issue and the serial "
                                  "Riccati chain, not by HBM (SURVEY.md F10, DESIGN.md §5)"},
