@@ -69,8 +69,12 @@ def cpu_baseline(cfg, x0, xs, obs, min_seconds=1.5):
         dt = time.perf_counter() - t0
         if dt >= min_seconds:          # ~16 threads x 1.5 s = about 25 core-seconds of CPU work
             break
-    return {"value": solved / dt, "unit": "solves/s", "cores": cores, "kind": "port",
-            "sample": "%d x first %d instances of the step's batch, OpenMP over instances, %.1f s wall (%.0f core-s)" % (reps, n, dt, dt * cores),
+    m = min(len(x0), 24)                                  # single-thread latency per solve
+    t1 = time.perf_counter()
+    oracle.solve(cfg, x0[:m], xs[:m], obs[:m], threads=1, want_multipliers=False)
+    lat_ms = 1e3 * (time.perf_counter() - t1) / m
+    return {"value": solved / dt, "unit": "solves/s", "cores": cores, "kind": "port", "single_thread_ms_per_instance": lat_ms,
+            "sample": "%d x first %d instances of the step's batch, OpenMP over instances, %.1f s wall (%.0f core-s); latency: %d instances on one thread" % (reps, n, dt, dt * cores, m),
             "note": "own FP64 C++ restatement of the NLP + IPOPT-style solver; CasADi+IPOPT baseline unavailable (casadi not installed)"}
 
 
@@ -109,6 +113,9 @@ def main():
                     help="BASELINE.json config: C2 (default, the metric's config) kin+1 static obstacle B=4096; C3 kin+3 predicted "
                          "obstacles B=32768; C4 dyn N=40 3 obstacles B=8192/GPU; C5 closed loop 80 steps (solves = scenes x steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--warm", action="store_true",
+                    help="C2/C3/C4 only: time the NEXT receding-horizon step, started from the shifted solution of a cold solve "
+                         "(main_cbf_kin_c_sim.py:16-26,92) instead of the cold start z0=0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,8 +173,23 @@ def main():
     else:
         d_z = bs.device_array((B, nz)); z_ptr = d_z
 
+    d_z0 = None
+    if args.warm:
+        # one cold solve, then the reference's shift: x0 <- X_1 (the plant is the model's own Euler step), U <- [U_1.., U_N-1, U_N-1],
+        # X <- [X_1.., X_N, X_N]; instances the cold solve did not finish keep their cold start
+        N = cfg.N
+        cold = bs.solve_batch(x0, xs, obs)            # (C3: the predicted obstacle trajectories are kept as they are)
+        Z = cold["z"]; ok = cold["status"] == 0
+        U = Z[:, :2 * N].reshape(B, N, 2); X = Z[:, 2 * N:].reshape(B, N + 1, nx)
+        z0 = np.concatenate([np.concatenate([U[:, 1:], U[:, -1:]], 1).reshape(B, -1), np.concatenate([X[:, 1:], X[:, -1:]], 1).reshape(B, -1)], 1)
+        z0[~ok] = 0.0
+        x0 = np.where(ok[:, None], X[:, 1], x0)
+        d_x0.upload(x0)
+        d_z0 = bs.device_array((B, nz)).upload(z0)
+        workload = workload.replace("cold start z0=0", "cold start").replace("cold start", "WARM start: next receding-horizon step from the shifted previous solution")
+
     def step():
-        bs.solve_device(B, d_x0, d_xs, d_obs, obs_kind, None, z_ptr, d_obj, d_st, d_it, d_kkt)
+        bs.solve_device(B, d_x0, d_xs, d_obs, obs_kind, d_z0, z_ptr, d_obj, d_st, d_it, d_kkt)
         if use_dist:
             bs.sync()                                   # the solve runs on the library's own stream
             dist.all_gather_into_tensor(z_all, z_local)
@@ -192,11 +214,18 @@ def main():
 
     status = d_st.download(); iters = d_it.download()
     solved = int((status == 0).sum())
+    dt_nogather = None
+    if use_dist:    # the same K steps once more without the gather, reported next to the headline value
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            bs.solve_device(B, d_x0, d_xs, d_obs, obs_kind, d_z0, z_ptr, d_obj, d_st, d_it, d_kkt)
+        fence()
+        dt_nogather = time.perf_counter() - t1
     if use_dist:
-        t = torch.tensor([dt, float(solved), float(tm["total_ms"])], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(solved), float(tm["total_ms"]), dt_nogather], dtype=torch.float64, device="cuda")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_max = float(tmax[0]); solved_all = int(round(float(tsum[1])))
+        dt_max = float(tmax[0]); solved_all = int(round(float(tsum[1]))); dt_nogather = float(tmax[3])
     else:
         dt_max = dt; solved_all = solved
 
@@ -213,7 +242,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "batch_per_gpu": B, "solved_per_step": solved_all, "failed_per_step": world * B - solved_all,
                        "iters_mean_solved": float(it_ok.mean()) if len(it_ok) else None, "iters_max": int(iters.max()),
-                       "tol": cfg.tol, "collective": "rccl all_gather of z per step" if use_dist else "none"},
+                       "tol": cfg.tol, "collective": "rccl all_gather of z per step" if use_dist else "none",
+                       "value_without_gather": (solved_all * args.steps / dt_nogather) if dt_nogather else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "mpcb_kernel_%s<%d>" % ("dyn" if cfg.model == _abi.MODEL_DYN else "kin", 1 if cfg.n_obs <= 1 else 3), "kernel_ms_avg": kernel_ms,
                          "algorithmic_bytes_per_launch": abytes,
