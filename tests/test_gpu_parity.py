@@ -239,8 +239,9 @@ def test_closed_loop_on_device_matches_host_loop(gpu_solver_factory):
 
 
 def test_driver_counterparts_run(tmp_path):
-    """The shipped counterparts of main_cbf_kin_c_sim.py / _pre.py / main_kin_s_sim.py: host loop == device loop, the
-    ego passes the obstacle without entering the keep-out ellipse."""
+    """The shipped counterparts of all five reference drivers (main_cbf_kin_c_sim.py / _pre.py / main_kin_s_sim.py /
+    main_kin_c_sim.py / main_cbf_dyn_c_sim.py): host loop == device loop, the ego passes the obstacle without entering the
+    keep-out ellipse."""
     from mpc_motion_planning_amd.sim import main_cbf_kin_c_sim, main_cbf_kin_c_sim_pre, main_kin_s_sim
     xh, uh = main_cbf_kin_c_sim.main(["--sim-time", "3.0"])
     xd, ud = main_cbf_kin_c_sim.main(["--sim-time", "3.0", "--device-loop"])
@@ -250,6 +251,12 @@ def test_driver_counterparts_run(tmp_path):
     assert h.min() >= -1e-6 and xp[-1, 0] > 30
     z = main_kin_s_sim.main()
     assert z.shape == (184, 1)
+    from mpc_motion_planning_amd.sim import main_cbf_dyn_c_sim, main_kin_c_sim
+    xk, uk = main_kin_c_sim.main(["--sim-time", "1.0"])                   # main_kin_c_sim.py: no obstacle, 10 steps
+    assert xk.shape == (11, 4) and uk.shape == (10, 2) and xk[-1, 0] > 15 and np.all(np.abs(uk[:, 1]) <= 3 + 1e-6)
+    xq, uq = main_cbf_dyn_c_sim.main(["--sim-time", "1.5"])               # main_cbf_dyn_c_sim.py incl. the zeroed control at step 10
+    assert xq.shape == (16, 6) and np.all(uq[10] == 0.0) and xq[-1, 0] > 10
+    assert (((xq[:, 0] - 100) / 4.0) ** 2 + ((xq[:, 1] + 3.5) / 1.0) ** 2 - 1).min() >= 0
 
 
 TOL_Z_DYN = 1e-4   # north_star's bound; the dyn cost has weights of 1 on vy and r, so IPOPT's scaled tolerance ball is wider
