@@ -637,6 +637,9 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           for (int r = 0; r < NX; ++r) { e.cw[r] = ent[sCW[r] + s]; e.cm[r] = ent[sCM[r] + s]; }
           e.start = ent[sStart + s]; e.hmat = ent[sHij + s];
         };
+        // gains of the previous stage, stored one stage late: the selects and the two DS stores then issue while this stage
+        // waits for its P+ row instead of sitting between the P store and the next P+ read
+        double pK0 = 0, pK1 = 0, pkf0 = 0, pkf1 = 0;
         auto stage = [&](int s, const StageEnt& e, StageEnt& nxt) -> bool {
           // W = P+ [A B | d] (+ p+ in the affine column)      lane (i,j): row i of P+, column j
           const double* Pn = Pst + (s + 1) * PST;
@@ -644,6 +647,9 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
 #pragma unroll
           for (int r = 0; r < NX; ++r) Pr[r] = Pn[eiA * NA + r];
           const double w0 = Pn[uWOff];
+          MPCB_SCHED_FENCE();
+          fw[(s + 1) * FWS + kOff] = kRow1 ? pK1 : pK0;           // (the first stage of a sweep writes zeros into the unused row N)
+          fw[(s + 1) * FWS + kfOff] = kfLane1 ? pkf1 : pkf0;
           MPCB_SCHED_FENCE();
           // one FMA chain: a dependent v_fma_f64 issues after 5.6 ticks against 4.5 for an independent one (tools/ubench/
           // fma_latency.hip), so splitting the chain only adds the instruction that joins the halves
@@ -678,8 +684,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           const double K0j = -(i11 * M6j + i12 * M7j), K1j = -(i12 * M6j + i22 * M7j);
           Pst[s * PST + pOff] = Mx + M6i * K0j + M7i * K1j;                 // P_s (lanes i,j < 6), pad elsewhere
           Pst[s * PST + psOff] = acc + M6i * kf0 + M7i * kf1;               // p_s (affine lanes), pad slot elsewhere
-          fw[s * FWS + kOff] = kRow1 ? K1j : K0j;
-          fw[s * FWS + kfOff] = kfLane1 ? kf1 : kf0;
+          pK0 = K0j; pK1 = K1j; pkf0 = kf0; pkf1 = kf1;
           wv::sync();
           return okpd;                                   // a failed stage leaves garbage behind; the sweep is repeated with a larger delta_w
         };
@@ -705,6 +710,9 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
               if (pd && s >= 2) pd = stage(s - 2, eA, eB);
             }
           }
+          fw[kOff] = kRow1 ? pK1 : pK0;                           // gains of stage 0
+          fw[kfOff] = kfLane1 ? pkf1 : pkf0;
+          wv::sync();
         }
         if (pd) { fact_ok = true; if (dw > 0) dw_last = dw; break; }
         if (first_try) { dw = (dw_last == 0.0) ? DW_FIRST : fmax(DW_MIN, KW_MINUS * dw_last); first_try = false; }
