@@ -308,6 +308,26 @@ def test_dynamic_bicycle_on_device(gpu_solver_factory, oracle_mod):
         solver(x0=np.zeros((2 * N + 6 * (N + 1), 1)), p=np.concatenate((x0c, xsc)), lbg=bad_l, lbx=lbx, ubg=bad_u, ubx=ubx)
 
 
+def test_dynamic_bicycle_horizons_and_warm_start(gpu_solver_factory, oracle_mod):
+    """dyn kernel at the ends of the horizon range (N = 1, 2, 50, 63 = MPCB_N_MAX: LDS layout, partial loop trips) and from a
+    warm start (shifted previous solution, main_cbf_dyn_c_sim.py:16-26,80) against the oracle."""
+    x0, xs, obs = scenes.sample_c4(32, seed=9, n_obs=1)
+    for N in (1, 2, 50, 63):
+        cfg = default_config(model=_abi.MODEL_DYN, N=N, n_obs=1)
+        agree(gpu_solver_factory(cfg).solve_batch(x0, xs, obs), oracle_mod.solve(cfg, x0, xs, obs), tol=TOL_Z_DYN, min_same_status=0.9)
+    cfg = default_config(model=_abi.MODEL_DYN, N=40, n_obs=1)
+    bs = gpu_solver_factory(cfg)
+    cold = bs.solve_batch(x0, xs, obs)
+    ok = cold["status"] == 0
+    assert ok.mean() > 0.8
+    N = 40
+    U = cold["z"][:, :2 * N].reshape(-1, N, 2); X = cold["z"][:, 2 * N:].reshape(-1, N + 1, 6)
+    z0 = np.concatenate([np.concatenate([U[:, 1:], U[:, -1:]], 1).reshape(len(U), -1), np.concatenate([X[:, 1:], X[:, -1:]], 1).reshape(len(U), -1)], 1)
+    x1 = X[:, 1].copy()
+    g = bs.solve_batch(x1[ok], xs[ok], obs[ok], z0=z0[ok]); r = oracle_mod.solve(cfg, x1[ok], xs[ok], obs[ok], z0[ok])
+    agree(g, r, tol=TOL_Z_DYN, min_same_status=0.9)           # (a primal-only warm start does not save iterations on this model)
+
+
 @pytest.mark.parametrize("model,n_obs", [(0, 0), (0, 2), (0, 3), (0, 5), (0, 8), (1, 0), (1, 2), (1, 5), (1, 8)])
 def test_every_kernel_instantiation_full_outputs(gpu_solver_factory, oracle_mod, model, n_obs):
     """Each compiled kernel variant (kin<0,1,3,8>, dyn<1,3,8>) with every output array against the oracle — catches
