@@ -412,6 +412,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
 
 #pragma clang loop unroll(disable)
     for (iters = 0;; ++iters) {
+      MPCB_STAMP(t_a);
       // tyre forces and trig at the iterate are recomputed here rather than kept across the line search (13 doubles/lane)
       DynEval ev; dyn_eval(c, X, U, ev);
       DynJac J; dyn_jac(c, X, ev, J);
@@ -567,6 +568,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         }
       }
 
+      MPCB_STAMP(t_b);
       // ----- factorisation with inertia correction ---------------------------------------------------------------------
       double dw = 0.0; bool first_try = true, fact_ok = false;
 #pragma clang loop unroll(disable)
@@ -637,7 +639,8 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         };
         bool pd = true;
 #pragma clang loop unroll(disable)
-        for (int s = N - 1; s >= 0 && pd; --s) pd = stage(s);       // one register set for the stage tables: the dyn kernel is register-bound
+        for (int s = N - 1; s >= 0 && pd; --s) pd = stage(s);       // one register set for the stage tables, loaded at the stage top: refilling
+                                                                    // it inside the stage (prefetch without a second set) still costs 64 B more scratch and 3 %
         if (pd) { fact_ok = true; if (dw > 0) dw_last = dw; break; }
         if (first_try) { dw = (dw_last == 0.0) ? DW_FIRST : fmax(DW_MIN, KW_MINUS * dw_last); first_try = false; }
         else dw *= (dw_last == 0.0) ? KW_PLUS_FIRST : KW_PLUS;
@@ -645,6 +648,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       }
       if (!fact_ok) { status = MPCB_ST_NUMERIC; break; }
 
+      MPCB_STAMP(t_c);
       // ----- forward roll-out of the step (per-stage numbers contiguous in fw, prefetched one stage ahead) -----------
       double dX[NX] = {0, 0, 0, 0, 0, 0}, dU[NU] = {0, 0};
       {
@@ -747,6 +751,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       } else a_min = G_THETA;
       a_min = wv::uni(a_min * G_ALPHA);
 
+      MPCB_STAMP(t_d);
       double alpha = a_pr; bool accepted = false, armijo_type = false;
       double Xt[NX], Ut[NU], dft[NX], sR0t, sR1t, rR0t, rR1t, sOt[NOB], rOt[NOB], upt0, upt1, tht = 0, ft = 0, lst = 0;
       DynEval et;
@@ -784,6 +789,10 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       if (a.trace && b == a.trace_instance && lane == 0) {
         double* t = a.trace + (size_t)iters * 8;
         t[4] = a_pr; t[5] = accepted ? alpha : 0.0; t[6] = a_du; t[7] = dw;
+#if defined(MPCB_STAMPS) && !defined(MPCB_WAVE_EMU)
+        MPCB_STAMP(t_e);
+        t[4] = (double)(t_b - t_a); t[5] = (double)(t_c - t_b); t[6] = (double)(t_d - t_c); t[7] = (double)(t_e - t_d);
+#endif
       }
       if (!accepted) { status = MPCB_ST_LINESEARCH; break; }
       if (!armijo_type) {

@@ -15,9 +15,15 @@ _lib.LIB_PATH = out
 from mpc_motion_planning_amd import scenes
 from mpc_motion_planning_amd.solver import BatchSolver, default_config
 
-cfg = default_config(N=30, T=0.1, n_obs=1)
+from mpc_motion_planning_amd import _abi
+if len(sys.argv) > 1 and sys.argv[1] == "dyn":
+    cfg = default_config(model=_abi.MODEL_DYN, N=40, T=0.1, n_obs=3)
+    x0, xs, obs = scenes.sample_c4(1, seed=3000, n_obs=3)
+    x0, xs = x0[0], xs[0]
+else:
+    cfg = default_config(N=30, T=0.1, n_obs=1)
+    x0, xs, obs = scenes.SHIPPED_X0, scenes.SHIPPED_XS, scenes.SHIPPED_OBS.reshape(1, 1, 6)
 bs = BatchSolver(cfg)
-x0, xs, obs = scenes.SHIPPED_X0, scenes.SHIPPED_XS, scenes.SHIPPED_OBS.reshape(1, 1, 6)
 r = bs.solve_trace(x0, xs, obs)
 tr = r["trace"][: int(r["iters"])]
 c = tr[:, 4:8]
