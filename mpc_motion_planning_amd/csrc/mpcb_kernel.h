@@ -628,9 +628,10 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         if (ei < NA && ej < NA) Pst[N * PST + ei * NA + ej] = ent[sHij + N];
         if (ei < NA && ej == 0) Pst[N * PST + PS_P + ei] = ent[sGi + N];
         wv::sync();
-        // Stage entries (18 table values per lane) do not depend on the recursion: they are prefetched one stage ahead
-        // into a second register set (ping-pong, no copies) so that only the P+ row and the W exchange sit on the
-        // critical path.  MPCB_SCHED_FENCE keeps the compiler from sinking the batched loads next to their uses.
+        // Stage entries (10 table values per lane) do not depend on the recursion: they are prefetched one stage ahead,
+        // into the SAME registers as soon as the running stage has spent them (no second set), so that only the P+ row and
+        // the W exchange sit on the critical path.  MPCB_SCHED_FENCE keeps the compiler from sinking the batched loads next
+        // to their uses.
         struct StageEnt { double cw[NX], cm[NX], start, hmat; };
         auto load_ent = [&](int s, StageEnt& e) {
 #pragma unroll
@@ -640,7 +641,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         // gains of the previous stage, stored one stage late: the selects and the two DS stores then issue while this stage
         // waits for its P+ row instead of sitting between the P store and the next P+ read
         double pK0 = 0, pK1 = 0, pkf0 = 0, pkf1 = 0;
-        auto stage = [&](int s, const StageEnt& e, StageEnt& nxt) -> bool {
+        auto stage = [&](int s, StageEnt& e) -> bool {
           // W = P+ [A B | d] (+ p+ in the affine column)      lane (i,j): row i of P+, column j
           const double* Pn = Pst + (s + 1) * PST;
           double Pr[NX];
@@ -670,11 +671,11 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           // rows 6,7 of M at column j and at column i (M is symmetric up to rounding)
           const double M6j = wv::shfl(Mx, NA * 8 + ej), M7j = wv::shfl(Mx, (NA + 1) * 8 + ej);
           const double M6i = wv::shfl(Mx, NA * 8 + ei), M7i = wv::shfl(Mx, (NA + 1) * 8 + ei);
-          // prefetch for the next stage behind the exchanges of this one: the DS queue is in order, so these 14 reads must
-          // not sit in front of the W / M traffic of the recursion (index -1 after stage 0 reads the tail of the filter
-          // region: in bounds, never used)
+          // e is spent.  Prefetch for the next stage behind the exchanges of this one: the DS queue is in order, so these 10
+          // reads must not sit in front of the W / M traffic of the recursion (index -1 after stage 0 reads the tail of the
+          // filter region: in bounds, never used)
           MPCB_SCHED_FENCE();
-          load_ent(s - 1, nxt);
+          load_ent(s - 1, e);
           MPCB_SCHED_FENCE();
           const double det = m11 * m22 - m12 * m12, dmar = det - 1e-14 * m11 * m22;
           const bool okpd = (m11 > 0) & (dmar > 0) & (dmar < 1e300);                    // wave-uniform; false for NaN / inf
@@ -690,24 +691,24 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         };
         bool pd = true;
         {
-          StageEnt eA, eB;
+          StageEnt eA;
           load_ent(N - 1, eA);
           int s = N - 1;
           // four stages per trip: the per-lane table addresses (10 registers) advance once per trip, the stages in between
           // use immediate offsets
 #pragma clang loop unroll(disable)
           for (; s >= 3 && pd; s -= 4) {
-            const bool p1 = stage(s, eA, eB);
-            const bool p2 = stage(s - 1, eB, eA);
-            const bool p3 = stage(s - 2, eA, eB);
-            const bool p4 = stage(s - 3, eB, eA);
+            const bool p1 = stage(s, eA);
+            const bool p2 = stage(s - 1, eA);
+            const bool p3 = stage(s - 2, eA);
+            const bool p4 = stage(s - 3, eA);
             pd = p1 & p2 & p3 & p4;
           }
           if (pd && s >= 0) {
-            pd = stage(s, eA, eB);
+            pd = stage(s, eA);
             if (pd && s >= 1) {
-              pd = stage(s - 1, eB, eA);
-              if (pd && s >= 2) pd = stage(s - 2, eA, eB);
+              pd = stage(s - 1, eA);
+              if (pd && s >= 2) pd = stage(s - 2, eA);
             }
           }
           fw[kOff] = kRow1 ? pK1 : pK0;                           // gains of stage 0
