@@ -166,10 +166,11 @@ def main():
     d_obs = bs.device_array(obs.shape).upload(obs)
     d_obj = bs.device_array((B,)); d_kkt = bs.device_array((B, 4))
     d_st = bs.device_array((B,), np.int32); d_it = bs.device_array((B,), np.int32)
-    if use_dist:    # z lives in a torch tensor so that RCCL can gather it; the solver only sees its raw pointer
-        z_local = torch.empty((B, nz), dtype=torch.float64, device="cuda")
+    if use_dist:    # z lives in torch tensors so that RCCL can gather it; the solver only sees their raw pointers
+        z_bufs = [torch.empty((B, nz), dtype=torch.float64, device="cuda") for _ in range(2)]     # double buffer: gather k overlaps solve k+1
         z_all = torch.empty((world * B, nz), dtype=torch.float64, device="cuda")
-        z_ptr = z_local.data_ptr()
+        z_local = z_bufs[0]; z_ptr = z_local.data_ptr()
+        pending = [None, None]; nstep = [0]
     else:
         d_z = bs.device_array((B, nz)); z_ptr = d_z
 
@@ -189,14 +190,23 @@ def main():
         workload = workload.replace("cold start z0=0", "cold start").replace("cold start", "WARM start: next receding-horizon step from the shifted previous solution")
 
     def step():
-        bs.solve_device(B, d_x0, d_xs, d_obs, obs_kind, d_z0, z_ptr, d_obj, d_st, d_it, d_kkt)
-        if use_dist:
-            bs.sync()                                   # the solve runs on the library's own stream
-            dist.all_gather_into_tensor(z_all, z_local)
+        if not use_dist:
+            bs.solve_device(B, d_x0, d_xs, d_obs, obs_kind, d_z0, z_ptr, d_obj, d_st, d_it, d_kkt)
+            return
+        # N > 1: the gather of step k runs on RCCL's stream while the solve of step k+1 runs on the library's stream
+        i = nstep[0] & 1; nstep[0] += 1
+        if pending[i] is not None:                      # the gather that last read this buffer (two steps ago) must be done
+            pending[i].wait(); torch.cuda.current_stream().synchronize()
+        bs.solve_device(B, d_x0, d_xs, d_obs, obs_kind, d_z0, z_bufs[i].data_ptr(), d_obj, d_st, d_it, d_kkt)
+        bs.sync()                                       # host waits for the solve only (it runs on the library's own stream)
+        pending[i] = dist.all_gather_into_tensor(z_all, z_bufs[i], async_op=True)
 
     def fence():
         bs.sync()
         if use_dist:
+            for w in pending:
+                if w is not None:
+                    w.wait()
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -242,7 +252,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "batch_per_gpu": B, "solved_per_step": solved_all, "failed_per_step": world * B - solved_all,
                        "iters_mean_solved": float(it_ok.mean()) if len(it_ok) else None, "iters_max": int(iters.max()),
-                       "tol": cfg.tol, "collective": "rccl all_gather of z per step" if use_dist else "none",
+                       "tol": cfg.tol, "collective": "rccl all_gather of z per step, overlapped with the next step's solve" if use_dist else "none",
                        "value_without_gather": (solved_all * args.steps / dt_nogather) if dt_nogather else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "mpcb_kernel_%s<%d>" % ("dyn" if cfg.model == _abi.MODEL_DYN else "kin", 1 if cfg.n_obs <= 1 else 3), "kernel_ms_avg": kernel_ms,
@@ -257,6 +267,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, x0, xs, obs)
         print(json.dumps(out))
     if use_dist:
+        z_local = z_bufs[(nstep[0] - 1) & 1]
         if rank == 0 and world == 1:      # rehearsal: the gathered block must equal what the solver wrote
             assert torch.equal(z_all[:B], z_local), "all_gather result differs from the solver output"
         dist.barrier()
