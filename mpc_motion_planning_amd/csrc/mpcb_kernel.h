@@ -74,8 +74,11 @@ enum KinEnt {
 //                    d0..d3, then 4 pad slots for the K stores of lanes without a K entry
 constexpr int PST = 48, PS_P = 36, PS_ZERO = 42, PS_PADP = 43, PS_PAD = 44;
 constexpr int FWS = 28, FW_KFF = 12, FW_A = 14, FW_D = 20, FW_PAD = 24, WSZ = 72, W_ZERO = 64;
+// constant block: uniform numbers of the instance that the node-parallel phases read from LDS (one ds_read, short live range)
+// instead of holding ~25 SGPR pairs through the whole solve
+constexpr int CS_WQ = 0, CS_WR = 4, CS_WDR = 6, CS_Q = 8, CS_R = 12, CS_DR = 14, CS_UL = 16, CS_XS = 18, CSZ = 24;
 struct Layout {
-  int ld, ent, Pst, fw, W, filt, zbuf, total;
+  int ld, ent, Pst, fw, W, cst, filt, zbuf, total;
 };
 MPCB_HD Layout layout_kin(int N, int nz) {
   Layout L;
@@ -85,6 +88,7 @@ MPCB_HD Layout layout_kin(int N, int nz) {
   L.Pst = o; o += N1 * PST;          // first: 16-byte aligned rows for wide LDS reads
   L.fw = o; o += N1 * FWS;
   L.W = o; o += WSZ;                 // W^T (8 columns x 6) + 16 pad slots + a permanent 0.0 (W_ZERO)
+  L.cst = o; o += CSZ;
   L.filt = o; o += 2 * FILTER_MAX;
   L.ent = o; o += KIN_NENT * L.ld;
   L.zbuf = L.Pst;                    // staging of z rows aliases the Riccati storage (used before / after the loop)
@@ -234,6 +238,14 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     g = wv::uni(wv::max(g));
     os = wv::uni((g > c.max_gradient) ? c.max_gradient / g : 1.0);
   }
+  double* cst = lds + L.cst;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { cst[CS_WQ + i] = os * 2 * c.Q[i]; cst[CS_Q + i] = c.Q[i]; cst[CS_XS + i] = xs[i]; }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) { cst[CS_WR + i] = os * 2 * c.R[i]; cst[CS_WDR + i] = os * 2 * c.DR[i]; cst[CS_R + i] = c.R[i]; cst[CS_DR + i] = c.DR[i]; cst[CS_UL + i] = c.u_last[i]; }
+  }
+  wv::sync();
   // pin node 0
   if (k == 0) {
 #pragma unroll
@@ -346,11 +358,11 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     for (int j = 0; j < NOBS; ++j) { rOa[j] = 0; if (ro_on[j]) { bar(qO, sOa[j]); rOa[j] = hval(j, Xa[0], Xa[1]) - sOa[j]; th += fabs(rOa[j]); } }
     if (hasu) {   // objective terms of stage k (kin.py:195-205)
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { const double e = Xa[i] - xs[i]; fl += c.Q[i] * e * e; }
-      fl += c.R[0] * Ua[0] * Ua[0] + c.R[1] * Ua[1] * Ua[1];
+      for (int i = 0; i < NX; ++i) { const double e = Xa[i] - cst[CS_XS + i]; fl += cst[CS_Q + i] * e * e; }
+      fl += cst[CS_R] * Ua[0] * Ua[0] + cst[CS_R + 1] * Ua[1] * Ua[1];
       if (k > 0 || c.du0_cost) {
-        const double d0 = Ua[0] - (k ? up0 : c.u_last[0]), d1 = Ua[1] - (k ? up1 : c.u_last[1]);
-        fl += c.DR[0] * d0 * d0 + c.DR[1] * d1 * d1;
+        const double d0 = Ua[0] - (k ? up0 : cst[CS_UL]), d1 = Ua[1] - (k ? up1 : cst[CS_UL + 1]);
+        fl += cst[CS_DR] * d0 * d0 + cst[CS_DR + 1] * d1 * d1;
       }
     }
     return ok;
@@ -484,7 +496,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         if (xnode) {
           if (k < N) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) rX[i] += os * 2 * c.Q[i] * (X[i] - xs[i]);
+            for (int i = 0; i < NX; ++i) rX[i] += cst[CS_WQ + i] * (X[i] - cst[CS_XS + i]);
           }
 #pragma unroll
           for (int i = 0; i < NX; ++i) { rX[i] -= lam[i]; sum_lam += fabs(lam[i]); }
@@ -495,12 +507,12 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           }
         }
         if (hasu) {
-          rU[0] += os * 2 * c.R[0] * U[0]; rU[1] += os * 2 * c.R[1] * U[1];
+          rU[0] += cst[CS_WR] * U[0]; rU[1] += cst[CS_WR + 1] * U[1];
           if (k > 0 || c.du0_cost) {
-            rU[0] += os * 2 * c.DR[0] * (U[0] - (k ? Up0 : c.u_last[0]));
-            rU[1] += os * 2 * c.DR[1] * (U[1] - (k ? Up1 : c.u_last[1]));
+            rU[0] += cst[CS_WDR] * (U[0] - (k ? Up0 : cst[CS_UL]));
+            rU[1] += cst[CS_WDR + 1] * (U[1] - (k ? Up1 : cst[CS_UL + 1]));
           }
-          if (k + 1 < N) { rU[0] -= os * 2 * c.DR[0] * (Un0 - U[0]); rU[1] -= os * 2 * c.DR[1] * (Un1 - U[1]); }
+          if (k + 1 < N) { rU[0] -= cst[CS_WDR] * (Un0 - U[0]); rU[1] -= cst[CS_WDR + 1] * (Un1 - U[1]); }
           rU[0] += b20 * ln[2]; rU[1] += T * ln[3];
           if (k + 1 < N) rU[0] += yRn;                                          // d(row k+1)/dU_k = -1
         }
@@ -560,16 +572,16 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       {
         double g[NW] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (xcost) {
-          hxx += os * 2 * c.Q[0]; hyy += os * 2 * c.Q[1]; hpp += os * 2 * c.Q[2]; hvv += os * 2 * c.Q[3];
+          hxx += cst[CS_WQ]; hyy += cst[CS_WQ + 1]; hpp += cst[CS_WQ + 2]; hvv += cst[CS_WQ + 3];
 #pragma unroll
-          for (int i = 0; i < NX; ++i) g[i] += os * 2 * c.Q[i] * (X[i] - xs[i]);
+          for (int i = 0; i < NX; ++i) g[i] += cst[CS_WQ + i] * (X[i] - cst[CS_XS + i]);
         }
         if (hasu) {
-          hdd += os * 2 * c.R[0]; haa += os * 2 * c.R[1];
-          g[6] += os * 2 * c.R[0] * U[0]; g[7] += os * 2 * c.R[1] * U[1];
+          hdd += cst[CS_WR]; haa += cst[CS_WR + 1];
+          g[6] += cst[CS_WR] * U[0]; g[7] += cst[CS_WR + 1] * U[1];
           if (k > 0 || c.du0_cost) {
-            const double w0 = os * 2 * c.DR[0], w1 = os * 2 * c.DR[1];
-            const double d0 = U[0] - (k ? Up0 : c.u_last[0]), d1 = U[1] - (k ? Up1 : c.u_last[1]);
+            const double w0 = cst[CS_WDR], w1 = cst[CS_WDR + 1];
+            const double d0 = U[0] - (k ? Up0 : cst[CS_UL]), d1 = U[1] - (k ? Up1 : cst[CS_UL + 1]);
             hdd += w0; h44 += w0; h46 -= w0; haa += w1; h55 += w1; h57 -= w1;
             g[6] += w0 * d0; g[4] -= w0 * d0; g[7] += w1 * d1; g[5] -= w1 * d1;
           }
@@ -800,13 +812,13 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         }
         if (xcost) {
 #pragma unroll
-          for (int i = 0; i < NX; ++i) d += os * 2 * c.Q[i] * (X[i] - xs[i]) * dX[i];
+          for (int i = 0; i < NX; ++i) d += cst[CS_WQ + i] * (X[i] - cst[CS_XS + i]) * dX[i];
         }
         if (hasu) {
-          d += os * 2 * c.R[0] * U[0] * dU[0] + os * 2 * c.R[1] * U[1] * dU[1];
+          d += cst[CS_WR] * U[0] * dU[0] + cst[CS_WR + 1] * U[1] * dU[1];
           if (k > 0 || c.du0_cost) {
-            d += os * 2 * c.DR[0] * (U[0] - (k ? Up0 : c.u_last[0])) * (dU[0] - (k ? dUp0 : 0.0));
-            d += os * 2 * c.DR[1] * (U[1] - (k ? Up1 : c.u_last[1])) * (dU[1] - (k ? dUp1 : 0.0));
+            d += cst[CS_WDR] * (U[0] - (k ? Up0 : cst[CS_UL])) * (dU[0] - (k ? dUp0 : 0.0));
+            d += cst[CS_WDR + 1] * (U[1] - (k ? Up1 : cst[CS_UL + 1])) * (dU[1] - (k ? dUp1 : 0.0));
           }
         }
         double ss[1] = {d}, mm[2] = {rpr, rdu};
