@@ -34,7 +34,9 @@ enum DynEnt {
 //   Pst [N+1][64]  P_k (8x8)          pst [N+1][10]  p_k (8), slot 8 = permanent 0.0, slot 9 pad
 //   fw  [N+1][DFWS] per-stage numbers of the forward roll-out, contiguous: K (2x8), kff (2), the 14 A entries, b4 b5, d (6), pad
 constexpr int DPSS = 10, DFWS = 44, DFW_KFF = 16, DFW_A = 18, DFW_B = 32, DFW_D = 34, DFW_PAD = 40, DWSZ = 64, DWU = 16 + 16;
-struct LayoutDyn { int ld, ent, Pst, pst, fw, W, Wu, filt, zbuf, total; };
+// constant block (as in the kin kernel): cost weights, reference state and last control, read from LDS by the node-parallel phases
+constexpr int DCS_WQ = 0, DCS_WR = 6, DCS_WDR = 8, DCS_Q = 10, DCS_R = 16, DCS_DR = 18, DCS_UL = 20, DCS_XS = 22, DCSZ = 28;
+struct LayoutDyn { int ld, ent, Pst, pst, fw, W, Wu, cst, filt, zbuf, total; };
 MPCB_HD LayoutDyn layout_dyn(int N) {
   LayoutDyn L;
   const int N1 = N + 1, NA = 8;
@@ -45,6 +47,7 @@ MPCB_HD LayoutDyn layout_dyn(int N) {
   L.fw = o; o += N1 * DFWS;
   L.W = o; o += DWSZ;
   L.Wu = o; o += DWU;
+  L.cst = o; o += DCSZ;
   L.filt = o; o += 2 * FILTER_MAX;
   L.ent = o; o += DYN_NENT * L.ld;
   L.zbuf = L.Pst;
@@ -199,6 +202,14 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
     g = wv::uni(wv::max(g));
     os = wv::uni((g > c.max_gradient) ? c.max_gradient / g : 1.0);
   }
+  double* cst = lds + L.cst;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { cst[DCS_WQ + i] = os * 2 * c.Q[i]; cst[DCS_Q + i] = c.Q[i]; cst[DCS_XS + i] = xs[i]; }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) { cst[DCS_WR + i] = os * 2 * c.R[i]; cst[DCS_WDR + i] = os * 2 * c.DR[i]; cst[DCS_R + i] = c.R[i]; cst[DCS_DR + i] = c.DR[i]; cst[DCS_UL + i] = c.u_last[i]; }
+  }
+  wv::sync();
   if (k == 0) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) X[i] = gx0[i];
@@ -305,11 +316,11 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
     if (isnode && !(Xa[3] > 0)) ok = false;              // vx must stay positive where the model is evaluated
     if (hasu) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { const double d = Xa[i] - xs[i]; fl += c.Q[i] * d * d; }
-      fl += c.R[0] * Ua[0] * Ua[0] + c.R[1] * Ua[1] * Ua[1];
+      for (int i = 0; i < NX; ++i) { const double d = Xa[i] - cst[DCS_XS + i]; fl += cst[DCS_Q + i] * d * d; }
+      fl += cst[DCS_R] * Ua[0] * Ua[0] + cst[DCS_R + 1] * Ua[1] * Ua[1];
       if (ducost) {
-        const double d0 = Ua[0] - (k ? up0 : c.u_last[0]), d1 = Ua[1] - (k ? up1 : c.u_last[1]);
-        fl += c.DR[0] * d0 * d0 + c.DR[1] * d1 * d1;
+        const double d0 = Ua[0] - (k ? up0 : cst[DCS_UL]), d1 = Ua[1] - (k ? up1 : cst[DCS_UL + 1]);
+        fl += cst[DCS_DR] * d0 * d0 + cst[DCS_DR + 1] * d1 * d1;
       }
     }
     return ok;
@@ -429,7 +440,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         if (xnode) {
           if (k < N) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) rX[i] += os * 2 * c.Q[i] * (X[i] - xs[i]);
+            for (int i = 0; i < NX; ++i) rX[i] += cst[DCS_WQ + i] * (X[i] - cst[DCS_XS + i]);
           }
 #pragma unroll
           for (int i = 0; i < NX; ++i) { rX[i] -= lam[i]; sum_lam += fabs(lam[i]); }
@@ -442,12 +453,12 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           }
         }
         if (hasu) {
-          rU[0] += os * 2 * c.R[0] * U[0]; rU[1] += os * 2 * c.R[1] * U[1];
+          rU[0] += cst[DCS_WR] * U[0]; rU[1] += cst[DCS_WR + 1] * U[1];
           if (ducost) {
-            rU[0] += os * 2 * c.DR[0] * (U[0] - (k ? Up0 : c.u_last[0]));
-            rU[1] += os * 2 * c.DR[1] * (U[1] - (k ? Up1 : c.u_last[1]));
+            rU[0] += cst[DCS_WDR] * (U[0] - (k ? Up0 : cst[DCS_UL]));
+            rU[1] += cst[DCS_WDR + 1] * (U[1] - (k ? Up1 : cst[DCS_UL + 1]));
           }
-          if (k + 1 < N) { rU[0] -= os * 2 * c.DR[0] * (Un0 - U[0]); rU[1] -= os * 2 * c.DR[1] * (Un1 - U[1]); }
+          if (k + 1 < N) { rU[0] -= cst[DCS_WDR] * (Un0 - U[0]); rU[1] -= cst[DCS_WDR + 1] * (Un1 - U[1]); }
           rU[0] += J.b4 * ln[4] + J.b5 * ln[5]; rU[1] += T * ln[3];
           if (k + 1 < N) { rU[0] += yR0n; rU[1] += yR1n; }
         }
@@ -511,14 +522,14 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         DynHess Hh = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (xcost) {
 #pragma unroll
-          for (int i = 0; i < NX; ++i) { hd[i] += os * 2 * c.Q[i]; g[i] += os * 2 * c.Q[i] * (X[i] - xs[i]); }
+          for (int i = 0; i < NX; ++i) { hd[i] += cst[DCS_WQ + i]; g[i] += cst[DCS_WQ + i] * (X[i] - cst[DCS_XS + i]); }
         }
         if (hasu) {
-          hd[8] += os * 2 * c.R[0]; hd[9] += os * 2 * c.R[1];
-          g[8] += os * 2 * c.R[0] * U[0]; g[9] += os * 2 * c.R[1] * U[1];
+          hd[8] += cst[DCS_WR]; hd[9] += cst[DCS_WR + 1];
+          g[8] += cst[DCS_WR] * U[0]; g[9] += cst[DCS_WR + 1] * U[1];
           if (ducost) {
-            const double w0 = os * 2 * c.DR[0], w1 = os * 2 * c.DR[1];
-            const double d0 = U[0] - (k ? Up0 : c.u_last[0]), d1 = U[1] - (k ? Up1 : c.u_last[1]);
+            const double w0 = cst[DCS_WDR], w1 = cst[DCS_WDR + 1];
+            const double d0 = U[0] - (k ? Up0 : cst[DCS_UL]), d1 = U[1] - (k ? Up1 : cst[DCS_UL + 1]);
             hd[8] += w0; hd[6] += w0; h68 -= w0; hd[9] += w1; hd[7] += w1; h79 -= w1;
             g[8] += w0 * d0; g[6] -= w0 * d0; g[9] += w1 * d1; g[7] -= w1 * d1;
           }
@@ -727,13 +738,13 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         }
         if (xcost) {
 #pragma unroll
-          for (int i = 0; i < NX; ++i) d += os * 2 * c.Q[i] * (X[i] - xs[i]) * dX[i];
+          for (int i = 0; i < NX; ++i) d += cst[DCS_WQ + i] * (X[i] - cst[DCS_XS + i]) * dX[i];
         }
         if (hasu) {
-          d += os * 2 * c.R[0] * U[0] * dU[0] + os * 2 * c.R[1] * U[1] * dU[1];
+          d += cst[DCS_WR] * U[0] * dU[0] + cst[DCS_WR + 1] * U[1] * dU[1];
           if (ducost) {
-            d += os * 2 * c.DR[0] * (U[0] - (k ? Up0 : c.u_last[0])) * (dU[0] - (k ? dUp0 : 0.0));
-            d += os * 2 * c.DR[1] * (U[1] - (k ? Up1 : c.u_last[1])) * (dU[1] - (k ? dUp1 : 0.0));
+            d += cst[DCS_WDR] * (U[0] - (k ? Up0 : cst[DCS_UL])) * (dU[0] - (k ? dUp0 : 0.0));
+            d += cst[DCS_WDR + 1] * (U[1] - (k ? Up1 : cst[DCS_UL + 1])) * (dU[1] - (k ? dUp1 : 0.0));
           }
         }
         double ss[1] = {d}, mm[2] = {rpr, rdu};
@@ -911,7 +922,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
                              J.a04 * ln[0] + J.a14 * ln[1] + J.a34 * ln[3] + J.a44 * ln[4] + J.a54 * ln[5],
                              T * ln[2] + J.a35 * ln[3] + J.a45 * ln[4] + J.a55 * ln[5]};
 #pragma unroll
-      for (int i = 0; i < NX; ++i) out[i] = -2 * c.Q[i] * (X[i] - xs[i]) - At[i] / os;
+      for (int i = 0; i < NX; ++i) out[i] = -2 * c.Q[i] * (X[i] - cst[DCS_XS + i]) - At[i] / os;
     }
     if (xcost) {
       int q = 0;
