@@ -12,9 +12,12 @@ cfg = default_config(N=N, T=0.1, n_obs=1)
 bs = BatchSolver(cfg)
 x0, xs, obs = scenes.sample_c2(B, seed=0)
 out = bs.solve_batch(x0, xs, obs)
+import time
 bs.timing(reset=True)
+t0 = time.perf_counter()
 for _ in range(reps):
     out = bs.solve_batch(x0, xs, obs)
+wall_ms = 1e3 * (time.perf_counter() - t0) / reps
 t = bs.timing(); n, tot = t['launches'], t['total_ms']
 solved = int((out["status"] == 0).sum())
-print(f"N={N} B={B} ms/launch={tot / n:.3f} solved={solved} iters_mean={out['iters'].mean():.2f} solves/s={solved / (tot / n) * 1e3:.0f}")
+print(f"N={N} B={B} host-pointer call {wall_ms:.3f} ms (PCIe both ways + sync) ms/launch={tot / n:.3f} solved={solved} iters_mean={out['iters'].mean():.2f} solves/s={solved / (tot / n) * 1e3:.0f}")
