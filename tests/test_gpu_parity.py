@@ -354,3 +354,12 @@ def test_every_kernel_instantiation_full_outputs(gpu_solver_factory, oracle_mod,
     sc_x = np.maximum(1.0, np.abs(r["lam_x"][both]).max(axis=1, keepdims=True))
     assert (np.abs(g["lam_x"][both] - r["lam_x"][both]) / sc_x).max() <= 1e-4
     assert np.abs(g["obj"][both] / r["obj"][both] - 1).max() <= 1e-8
+
+
+def test_fuzzed_structures_against_oracle(gpu_solver_factory):
+    """40 random NLP structures (model, N in 1..63, 0..8 obstacles, static / predicted, keep-out / CBF rows, terminal rows,
+    tolerance, start) through the HIP library and the oracle: tools/fuzz_gpu_vs_oracle.py with a fixed seed."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_gpu_vs_oracle", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_gpu_vs_oracle.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    assert mod.run(cases=40, seed=11, verbose=False) == 0

@@ -1,0 +1,74 @@
+"""Differential fuzz: random NLP structures (model, horizon, obstacle count / kind / row form, tolerance, start) solved by the
+HIP library and by the CPU oracle; reports every disagreement.  Run on a GPU box:
+    python tools/fuzz_gpu_vs_oracle.py [cases] [seed]
+Exit code 1 if any case disagrees beyond the test-suite tolerances (tests/test_gpu_parity.py, which also runs a short
+fixed-seed pass of `run`)."""
+import sys
+
+import numpy as np
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from mpc_motion_planning_amd import scenes, _abi                                  # noqa: E402
+from mpc_motion_planning_amd.solver import BatchSolver, default_config            # noqa: E402
+from oracle import oracle                                                         # noqa: E402
+
+
+def one_case(rng, c):
+    dyn = rng.random() < 0.35
+    N = int(rng.choice([1, 2, 3, 5, 8, 13, 20, 30, 31, 32, 33, 40, 50, 62, 63]))
+    n_obs = int(rng.choice([0, 1, 1, 2, 3, 3, 4, 5, 8]))
+    B = int(rng.choice([1, 3, 17, 64]))
+    seed = int(rng.integers(1 << 30))
+    kind = "static"
+    if dyn:
+        cfg = default_config(model=_abi.MODEL_DYN, N=N, n_obs=n_obs); tol = 1e-4
+        x0, xs, obs = scenes.sample_c4(B, seed=seed, n_obs=max(n_obs, 1)); obs = obs[:, :n_obs]
+    else:
+        cfg = default_config(N=N, n_obs=n_obs); tol = 1e-5
+        if n_obs == 0:
+            x0, xs, obs = scenes.sample_c2(B, seed=seed); obs = obs[:, :0]
+        else:
+            if rng.random() < 0.5:
+                kind = "predicted"
+            x0, xs, ob0, traj = scenes.sample_c3(B, N=N, dt=0.1, seed=seed, n_obs=n_obs)
+            obs = traj if kind == "predicted" else ob0
+        if n_obs and rng.random() < 0.3:
+            cfg.obs_mode = _abi.OBS_DCBF
+        if rng.random() < 0.2:
+            cfg.obs_terminal = 1
+    if rng.random() < 0.2:
+        cfg.tol = 1e-6
+    if rng.random() < 0.2 and not dyn:          # dyn from z0 = 0 without the roll-out starts at vx = bound_push (1/vx in the tyre
+        cfg.init_rollout = 0                     # model): both solvers fail there, in different ways
+    desc = "case %d: %s N=%d n_obs=%d(%s) B=%d mode=%d term=%d tol=%g rollout=%d" % (
+        c, "dyn" if dyn else "kin", N, n_obs, kind, B, cfg.obs_mode, cfg.obs_terminal, cfg.tol, cfg.init_rollout)
+    try:
+        bs = BatchSolver(cfg)
+    except Exception as e:                       # configurations the library refuses are refused by design; show them
+        return True, desc + " -> refused: " + str(e)[:80]
+    ob = obs if n_obs else None
+    g = bs.solve_batch(x0, xs, ob, multipliers=True)
+    r = oracle.solve(cfg, x0, xs, ob)
+    bs.close()
+    same = (g["status"] == r["status"]).mean()
+    both = (g["status"] == 0) & (r["status"] == 0)
+    err = np.abs(g["z"][both] - r["z"][both]).max() if both.any() else 0.0
+    ok = same >= 0.9 and err <= tol * (10 if cfg.tol > 1e-8 else 1) and bool(np.all(np.isfinite(g["z"])))
+    return ok, desc + " -> status agreement %.2f, solved %d/%d, L-inf(z) %.2e%s" % (same, int(both.sum()), B, err, "" if ok else "  <-- MISMATCH")
+
+
+def run(cases=60, seed=0, verbose=True):
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for c in range(cases):
+        ok, line = one_case(rng, c)
+        if verbose or not ok:
+            print(line)
+        bad += 0 if ok else 1
+    if verbose:
+        print("mismatching cases:", bad)
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 0) else 0)
