@@ -263,7 +263,7 @@ def main():
                               "unit": "TFLOP/s", "frac": flops / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                               "model": "56 kflop x interior-point iterations summed over the batch"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, x0, xs, obs)
         print(json.dumps(out))
     if use_dist:
