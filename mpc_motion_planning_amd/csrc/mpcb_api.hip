@@ -168,10 +168,12 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a) {
   if (h->cfg.model == MPCB_MODEL_DYN) {
     if (n <= 1) LAUNCH_DYN(1);
     else if (n <= 3) LAUNCH_DYN(3);
+    else if (n <= 5) LAUNCH_DYN(5);
     else LAUNCH_DYN(8);
   } else if (n == 0) LAUNCH(0);
   else if (n == 1) LAUNCH(1);
   else if (n <= 3) LAUNCH(3);
+  else if (n <= 5) LAUNCH(5);
   else LAUNCH(8);
 #undef LAUNCH
 #undef LAUNCH_DYN

@@ -330,7 +330,7 @@ def test_dynamic_bicycle_horizons_and_warm_start(gpu_solver_factory, oracle_mod)
 
 @pytest.mark.parametrize("model,n_obs", [(0, 0), (0, 2), (0, 3), (0, 5), (0, 8), (1, 0), (1, 2), (1, 5), (1, 8)])
 def test_every_kernel_instantiation_full_outputs(gpu_solver_factory, oracle_mod, model, n_obs):
-    """Each compiled kernel variant (kin<0,1,3,8>, dyn<1,3,8>) with every output array against the oracle — catches
+    """Each compiled kernel variant (kin<0,1,3,5,8>, dyn<1,3,5,8>) with every output array against the oracle — catches
     variant-specific code-generation problems (one was found in dyn<3>: a spilled LDS address of the output staging)."""
     rng = np.random.default_rng(100 + n_obs)
     B = 48
