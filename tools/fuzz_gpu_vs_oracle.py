@@ -53,7 +53,10 @@ def one_case(rng, c):
     same = (g["status"] == r["status"]).mean()
     both = (g["status"] == 0) & (r["status"] == 0)
     err = np.abs(g["z"][both] - r["z"][both]).max() if both.any() else 0.0
-    ok = same >= 0.9 and err <= tol * (10 if cfg.tol > 1e-8 else 1) and bool(np.all(np.isfinite(g["z"])))
+    # what must agree: WHICH instances are solved (the way a failing instance fails — iteration cap, line search, numerics —
+    # may differ between two roundings of the same algorithm), allowing one borderline instance per batch
+    flips = int(((g["status"] == 0) != (r["status"] == 0)).sum())
+    ok = flips <= max(1, B // 10) and err <= tol * (10 if cfg.tol > 1e-8 else 1) and bool(np.all(np.isfinite(g["z"])))
     return ok, desc + " -> status agreement %.2f, solved %d/%d, L-inf(z) %.2e%s" % (same, int(both.sum()), B, err, "" if ok else "  <-- MISMATCH")
 
 
