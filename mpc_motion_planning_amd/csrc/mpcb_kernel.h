@@ -444,7 +444,8 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   const int uMOff = ei == 6 ? ej * NA + 4 : ei == 7 ? ej * NA + 5 : W_ZERO;
   // store targets; lanes without an entry write into pad slots, so that the sweep has no divergent branches
   const int wOff = ei < NA ? ej * NA + ei : NW * NA + (lane & 15);
-  const int pOff = (ei < NA && ej < NA) ? ei * NA + ej : PS_PAD + (lane & 3);
+  const bool upper = ei < NA && ej < NA && ei <= ej;
+  const int pOff = upper ? ei * NA + ej : PS_PAD + (lane & 1), pOffT = upper ? ej * NA + ei : PS_PAD + 2 + (lane & 1);
   const int psOff = (aff && ei < NA) ? PS_P + ei : PS_PADP;
   // gains: lanes (0,j) store K0j, lanes (1,j) store K1j (j < 6); lanes 62 / 63 store the feed-forward terms
   const int kOff = (ej < NA && ei == 0) ? ej : (ej < NA && ei == 1) ? NA + ej : FW_PAD + (lane & 1);
@@ -695,7 +696,13 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           const double i11 = m22 * idet, i12 = -m12 * idet, i22 = m11 * idet;
           const double kf0 = -(i11 * mu6 + i12 * mu7), kf1 = -(i12 * mu6 + i22 * mu7);
           const double K0j = -(i11 * M6j + i12 * M7j), K1j = -(i12 * M6j + i22 * M7j);
-          Pst[s * PST + pOff] = Mx + M6i * K0j + M7i * K1j;                 // P_s (lanes i,j < 6), pad elsewhere
+          // P_s: the lanes of the upper triangle (i <= j) store their entry to (i,j) AND (j,i), the lanes below the diagonal
+          // store into pad slots.  P(i,j) and P(j,i) are equal in exact arithmetic, but their cancellation errors (entries of
+          // 1e12 when bounds are active at mu -> 1e-9) differ, and without this mirroring the asymmetry compounds through the
+          // sweep: the positive-definiteness test turns noisy near convergence and delta_w escalates to 1e2 where 1e-2 does.
+          const double Pij = Mx + M6i * K0j + M7i * K1j;
+          Pst[s * PST + pOff] = Pij;
+          Pst[s * PST + pOffT] = Pij;
           Pst[s * PST + psOff] = acc + M6i * kf0 + M7i * kf1;               // p_s (affine lanes), pad slot elsewhere
           pK0 = K0j; pK1 = K1j; pkf0 = kf0; pkf1 = kf1;
           wv::sync();
@@ -863,8 +870,11 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
             bool sw = false;
             if (th0 <= theta_min && dphi < 0) sw = alpha * pow(-dphi, S_PHI) > DELTA * pow(th0, S_THETA);
             if (th0 <= theta_min && sw) {
-              if (phit <= phi0 + ETA_PHI * alpha * dphi || phit - phi0 <= 10 * 2.2e-16 * fabs(phi0)) { accepted = true; armijo_type = true; }
-            } else if (tht <= (1 - G_THETA) * th0 || phit <= phi0 - G_PHI * th0) accepted = true;
+              // IPOPT's Compare_le(lhs, rhs, base): lhs - rhs <= 10 eps |base| — round-off slack on both acceptance tests
+              // (ArmijoHolds / IsAcceptableToCurrentIterate in IpFilterLSAcceptor.cpp)
+              if ((phit - phi0) - ETA_PHI * alpha * dphi <= 10 * 2.220446049250313e-16 * fabs(phi0)) { accepted = true; armijo_type = true; }
+            } else if (tht - (1 - G_THETA) * th0 <= 10 * 2.220446049250313e-16 * fabs(th0) ||
+                       (phit - phi0) + G_PHI * th0 <= 10 * 2.220446049250313e-16 * fabs(phi0)) accepted = true;
           }
         }
         if (accepted) break;

@@ -31,9 +31,9 @@ enum DynEnt {
 };
 
 // LDS layout (doubles):
-//   Pst [N+1][64]  P_k (8x8)          pst [N+1][10]  p_k (8), slot 8 = permanent 0.0, slot 9 pad
+//   Pst [N+1][66]  P_k (8x8) + 2 pad   pst [N+1][10]  p_k (8), slot 8 = permanent 0.0, slot 9 pad
 //   fw  [N+1][DFWS] per-stage numbers of the forward roll-out, contiguous: K (2x8), kff (2), the 14 A entries, b4 b5, d (6), pad
-constexpr int DPSS = 10, DFWS = 44, DFW_KFF = 16, DFW_A = 18, DFW_B = 32, DFW_D = 34, DFW_PAD = 40, DWSZ = 64, DWU = 16 + 16;
+constexpr int DPST = 66 /* P_k 8x8 + 2 pad slots for the stores of the lanes below the diagonal */, DPSS = 10, DFWS = 44, DFW_KFF = 16, DFW_A = 18, DFW_B = 32, DFW_D = 34, DFW_PAD = 40, DWSZ = 64, DWU = 16 + 16;
 // constant block (as in the kin kernel): cost weights, reference state and last control, read from LDS by the node-parallel phases
 constexpr int DCS_WQ = 0, DCS_WR = 6, DCS_WDR = 8, DCS_Q = 10, DCS_R = 16, DCS_DR = 18, DCS_UL = 20, DCS_XS = 22, DCSZ = 28;
 struct LayoutDyn { int ld, ent, Pst, pst, fw, W, Wu, cst, filt, zbuf, total; };
@@ -42,7 +42,7 @@ MPCB_HD LayoutDyn layout_dyn(int N) {
   const int N1 = N + 1, NA = 8;
   L.ld = N1 | 1;
   int o = 0;
-  L.Pst = o; o += N1 * NA * NA;
+  L.Pst = o; o += N1 * DPST;
   L.pst = o; o += N1 * DPSS;
   L.fw = o; o += N1 * DFWS;
   L.W = o; o += DWSZ;
@@ -398,6 +398,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   const int kOff = (ei == 0) ? ej : (ei == 1) ? NA + ej : DFW_PAD + (lane & 1);
   const int kfOff = (lane == 62) ? DFW_KFF : (lane == 63) ? DFW_KFF + 1 : DFW_PAD + 2 + (lane & 1);
   const bool kRow1 = (ei == 1), kfLane1 = (lane == 63);
+  const int pOff = ei <= ej ? ei * NA + ej : NA * NA, pOffT = ei <= ej ? ej * NA + ei : NA * NA + 1;
   if (isnode) { ent[DE_ZERO * ld + k] = 0.0; ent[DE_ONE * ld + k] = 1.0; ent[DE_T * ld + k] = T; }
 
   double* Pst = lds + L.Pst; double* pst = lds + L.pst; double* fw = lds + L.fw;
@@ -592,7 +593,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         }
         wv::sync();
         // terminal: P_N = H_N (state block), p_N = g_N
-        Pst[N * NA * NA + ei * NA + ej] = ent[sHij + N];
+        Pst[N * DPST + ei * NA + ej] = ent[sHij + N];
         if (ej == 0) pst[N * DPSS + ei] = ent[(DE_G0 + ei) * ld + N];
         wv::sync();
         struct StageEnt { double abj[NX], abi[NX], start, hmat, startU, hU, startUU, b4, b5; };
@@ -605,7 +606,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         };
         auto stage = [&](int s) -> bool {
           StageEnt e; load_ent(s, e);
-          const double* Pn = Pst + (s + 1) * NA * NA + ei * NA;
+          const double* Pn = Pst + (s + 1) * DPST + ei * NA;
           double Pr[NA];
 #pragma unroll
           for (int r = 0; r < NA; ++r) Pr[r] = Pn[r];
@@ -641,7 +642,11 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           const double i11 = m22 * idet, i12 = -m12 * idet, i22 = m11 * idet;
           const double kf0 = -(i11 * mu8 + i12 * mu9), kf1 = -(i12 * mu8 + i22 * mu9);
           const double K0j = -(i11 * M8j + i12 * M9j), K1j = -(i12 * M8j + i22 * M9j);
-          Pst[s * NA * NA + ei * NA + ej] = Mx + M8i * K0j + M9i * K1j;
+          // upper-triangle lanes store to (i,j) and (j,i), the others into pad slots: P stays symmetric through the sweep (see
+          // the kinematic kernel: without it the asymmetry of the cancellation errors compounds and delta_w escalates)
+          const double Pij = Mx + M8i * K0j + M9i * K1j;
+          Pst[s * DPST + pOff] = Pij;
+          Pst[s * DPST + pOffT] = Pij;
           pst[s * DPSS + psOff] = acc + M8i * kf0 + M9i * kf1;
           fw[s * DFWS + kOff] = kRow1 ? K1j : K0j;
           fw[s * DFWS + kfOff] = kfLane1 ? kf1 : kf0;
@@ -700,7 +705,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       const double dUp0 = wv::shfl(dU[0], k - 1), dUp1 = wv::shfl(dU[1], k - 1);
       double lamF[NX] = {0, 0, 0, 0, 0, 0};
       if (xnode) {
-        const double* Pk = Pst + k * NA * NA;
+        const double* Pk = Pst + k * DPST;
         const double dxa[NA] = {dX[0], dX[1], dX[2], dX[3], dX[4], dX[5], dUp0, dUp1};
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -789,8 +794,11 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
             bool sw = false;
             if (th0 <= theta_min && dphi < 0) sw = alpha * pow(-dphi, S_PHI) > DELTA * pow(th0, S_THETA);
             if (th0 <= theta_min && sw) {
-              if (phit <= phi0 + ETA_PHI * alpha * dphi || phit - phi0 <= 10 * 2.2e-16 * fabs(phi0)) { accepted = true; armijo_type = true; }
-            } else if (tht <= (1 - G_THETA) * th0 || phit <= phi0 - G_PHI * th0) accepted = true;
+              // IPOPT's Compare_le(lhs, rhs, base): lhs - rhs <= 10 eps |base| — round-off slack on both acceptance tests
+              // (ArmijoHolds / IsAcceptableToCurrentIterate in IpFilterLSAcceptor.cpp)
+              if ((phit - phi0) - ETA_PHI * alpha * dphi <= 10 * 2.220446049250313e-16 * fabs(phi0)) { accepted = true; armijo_type = true; }
+            } else if (tht - (1 - G_THETA) * th0 <= 10 * 2.220446049250313e-16 * fabs(th0) ||
+                       (phit - phi0) + G_PHI * th0 <= 10 * 2.220446049250313e-16 * fabs(phi0)) accepted = true;
           }
         }
         if (accepted) break;

@@ -747,8 +747,11 @@ struct Solver {
       if (t.ok && t.theta <= theta_max && filter_ok(t.theta, t.phi)) {
         bool sw = dphi < 0 && alpha * std::pow(-dphi, o.s_phi) > o.delta * std::pow(th0, o.s_theta);
         if (th0 <= theta_min && sw) {
-          if (t.phi <= phi0 + o.eta_phi * alpha * dphi || t.phi - phi0 <= 10 * 2.2e-16 * std::fabs(phi0)) { armijo_type = true; return alpha; }
-        } else if (t.theta <= (1 - o.gamma_theta) * th0 || t.phi <= phi0 - o.gamma_phi * th0) return alpha;
+          // IPOPT's Compare_le(lhs, rhs, base): lhs - rhs <= 10 eps |base| (IpUtils.cpp), used by ArmijoHolds and
+          // IsAcceptableToCurrentIterate of IpFilterLSAcceptor.cpp: round-off slack on both acceptance tests
+          if ((t.phi - phi0) - o.eta_phi * alpha * dphi <= 10 * 2.220446049250313e-16 * std::fabs(phi0)) { armijo_type = true; return alpha; }
+        } else if (t.theta - (1 - o.gamma_theta) * th0 <= 10 * 2.220446049250313e-16 * std::fabs(th0) ||
+                   (t.phi - phi0) + o.gamma_phi * th0 <= 10 * 2.220446049250313e-16 * std::fabs(phi0)) return alpha;
       }
       alpha *= 0.5;
       if (alpha < a_min || alpha < 1e-16) return 0.0;
