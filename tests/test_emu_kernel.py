@@ -76,3 +76,15 @@ def test_emulated_dyn_kernel_and_closed_form_derivatives():
     e = emu.solve(cfg, x0, xs, obs); r = oracle.solve(cfg, x0, xs, obs)
     assert e["status"][0] == r["status"][0] == 0 and e["iters"][0] == r["iters"][0]
     assert np.abs(e["z"] - r["z"]).max() <= 1e-9 and np.abs(e["lam_g"] - r["lam_g"]).max() <= 1e-6 * np.abs(r["lam_g"]).max()
+
+
+def test_emulated_kernel_end_game_needs_symmetric_p():
+    """Five C3 instances (tests/golden/endgame_c3.npz, captured from a GPU run) that the device kernel failed with
+    MPCB_ST_LINESEARCH at mu = mu_floor while the oracle solved them: P(i,j) and P(j,i) were stored from two lanes with different
+    cancellation errors, the asymmetry compounded through the Riccati sweep and the inertia correction escalated.  With P
+    mirrored across the diagonal at the store the kernel converges like the oracle."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "endgame_c3.npz"))
+    cfg = product_cfg(30, 3)
+    e = emu.solve(cfg, d["x0"], d["xs"], d["obs"]); r = oracle.solve(cfg, d["x0"], d["xs"], d["obs"])
+    assert np.all(r["status"] == 0) and np.all(e["status"] == 0)
+    assert np.abs(e["iters"] - r["iters"]).max() <= 4 and np.abs(e["z"] - r["z"]).max() <= 1e-5
