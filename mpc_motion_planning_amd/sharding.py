@@ -6,7 +6,6 @@ solves its own slice with no data-path collective, and ONE all-gather at the end
 trajectories.  `torch.distributed` is plumbing only (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU
 tests); nothing here touches the solver.
 """
-import numpy as np
 
 
 def shard_bounds(B, world, rank):

@@ -30,7 +30,6 @@ def agree(gpu, ref, tol=TOL_Z, min_same_status=1.0):
 
 
 def test_native_library_is_the_one_running(gpu_solver_factory):
-    import ctypes
     from mpc_motion_planning_amd import _lib
     assert os.path.exists(_lib.LIB_PATH)
     maps = open("/proc/self/maps").read()

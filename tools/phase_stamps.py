@@ -3,7 +3,6 @@ Builds a second library with -DMPCB_STAMPS (never shipped) and runs the shipped 
     python tools/phase_stamps.py [kin|dyn]
 Columns: condense+KKT, Riccati sweep, forward+costates+ratios, line search (s_memtime ticks)."""
 import os, subprocess, sys
-import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 out = os.path.join(ROOT, "mpc_motion_planning_amd", "lib", "libmpcbatch_stamps.so")

@@ -2,7 +2,6 @@
     python tools/probe_batch.py N B [reps]
 Prints ms per launch (HIP events inside the library) and solved count."""
 import sys
-import numpy as np
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from mpc_motion_planning_amd import scenes
 from mpc_motion_planning_amd.solver import BatchSolver, default_config

@@ -1,7 +1,6 @@
 """Probe: kernel time vs number of obstacles (which NOBS template instance runs) for the kin solve, C3-style scenes.
     python tools/probe_nobs.py [B]"""
 import sys
-import numpy as np
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from mpc_motion_planning_amd import scenes, _abi
 from mpc_motion_planning_amd.solver import BatchSolver, default_config
