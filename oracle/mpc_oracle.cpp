@@ -228,8 +228,12 @@ struct Ineq {
   double r = 0;                  // c(w) - s   (0 for boxes)
   double ds = 0, dvL = 0, dvU = 0;
   double tL = 0, tU = 0;         // complementarity targets of the current solve
-  // gradient wrt the stage vector [X, Uprev, U]: at most two nonzeros
-  int i0 = -1, i1 = -1; double g0 = 0, g1 = 0;
+  // gradient wrt the stage vector [X, Uprev, U]: at most two nonzeros (i0,i1) — four (x, y, phi, v) for a general-gamma
+  // discrete-CBF row, which also carries its own 4x4 second derivative hc
+  int i0 = -1, i1 = -1, i2 = -1, i3 = -1; double g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+  double hc[4][4] = {{0}};
+  int idx(int a) const { return a == 0 ? i0 : a == 1 ? i1 : a == 2 ? i2 : i3; }
+  double gv(int a) const { return a == 0 ? g0 : a == 1 ? g1 : a == 2 ? g2 : g3; }
   double y() const { return (hasL ? vL : 0.0) - (hasU ? vU : 0.0); }
 };
 
@@ -296,6 +300,27 @@ struct Solver {
     double dx = Xk[0] - q.ox, dy = Xk[1] - q.oy;
     return dx * dx * q.ix2 + dy * dy * q.iy2 - 1.0;
   }
+  // General discrete-CBF row (kin.py:248, commented form, 0 < gamma < 1):  gamma h(X_i) + h(X_{i+1}) - h(X_i) >= 0 with the
+  // stage-i obstacle in both terms.  On the feasible set X_{i+1} = F(X_i,U_i), and the position part of the Euler step depends
+  // on X_i only, so the row is the STATE constraint  c_i(X_i) = h(X_i + T f(X_i)) - (1 - gamma) h(X_i) >= gamma hmin  of node i:
+  // same feasible set, same minimisers; the multipliers of the reference form follow from these (see write_outputs).
+  bool gen() const { return c.model == MPCB_MODEL_KIN && c.obs_mode == MPCB_OBS_DCBF && c.gamma < 1.0 - 1e-12; }
+  template <class S> S crow(int k, int j, const S* x) const {   // x = (x, y, phi, v)
+    const ObsP& q = obs[k][j];
+    S qx = x[0] + c.T * (x[3] * cos(x[2])), qy = x[1] + c.T * (x[3] * sin(x[2]));
+    S a = qx - q.ox, b = qy - q.oy, d = x[0] - q.ox, e = x[1] - q.oy;
+    S hq = a * a * q.ix2 + b * b * q.iy2 - 1.0, hp = d * d * q.ix2 + e * e * q.iy2 - 1.0;
+    return hq - (1.0 - c.gamma) * hp;
+  }
+  double rowval(int k, int j, const double* Xk) const { return gen() ? crow<double>(k, j, Xk) : hval(k, j, Xk); }
+  void row_derivs(int k, int j, const double* Xk, Ineq& it) const {
+    const ObsP& q = obs[k][j];
+    if (!gen()) { it.g0 = 2 * (Xk[0] - q.ox) * q.ix2; it.g1 = 2 * (Xk[1] - q.oy) * q.iy2; return; }
+    D2<4> x[4]; for (int i = 0; i < 4; ++i) x[i] = D2<4>::var(Xk[i], i);
+    D2<4> v = crow<D2<4>>(k, j, x);
+    it.g0 = v.g[0]; it.g1 = v.g[1]; it.g2 = v.g[2]; it.g3 = v.g[3];
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) it.hc[a][b] = v.h[a][b];
+  }
 
   static void relax(const mpcb_config& c, Ineq& it) {
     if (it.hasL) it.L -= c.bound_relax * std::max(1.0, std::fabs(it.L));
@@ -326,6 +351,7 @@ struct Solver {
       obs_node[k] = false;
       int step;                                             // obstacle sample used by the row at node k
       if (c.obs_mode == MPCB_OBS_KEEPOUT) { obs_node[k] = (k <= last_row); step = k; }
+      else if (gen()) { obs_node[k] = (k <= N - 1); step = k; }             // row i is c_i(X_i), i = 0..N-1
       else { obs_node[k] = (k >= 1 && k - 1 <= last_row); step = k - 1; }   // gamma = 1: row i is h_i(X_{i+1})
       if (!obs_node[k] || nobs == 0) continue;
       for (int j = 0; j < nobs; ++j) {
@@ -373,7 +399,7 @@ struct Solver {
     for (int i = 0; i < nx; ++i)
       if (x0[i] < c.x_lo[i] - 1e-8 || x0[i] > c.x_hi[i] + 1e-8) { status = MPCB_ST_INFEASIBLE_X0; return false; }
     if (obs_node[0]) for (int j = 0; j < nobs; ++j)
-      if (hval(0, j, x0) < c.obs_hmin - 1e-8) { status = MPCB_ST_INFEASIBLE_X0; return false; }
+      if (rowval(0, j, x0) < (gen() ? c.gamma : 1.0) * c.obs_hmin - 1e-8) { status = MPCB_ST_INFEASIBLE_X0; return false; }
 
     // boxes: relax (bound_relax_factor), push the start inside (bound_push / bound_frac), duals = 1
     for (int k = 0; k <= N; ++k) {
@@ -399,8 +425,9 @@ struct Solver {
       for (int j = 0; j < NOBM; ++j) {
         Ineq& it = rO[k][j]; it = Ineq();
         if (!(j < nobs && k >= 1 && obs_node[k])) continue;
-        setup(it, c.obs_hmin, INF);
-        relax(c, it); it.s = push(it, hval(k, j, X[k])); it.vL = 1.0; it.i0 = 0; it.i1 = 1;
+        setup(it, (gen() ? c.gamma : 1.0) * c.obs_hmin, INF);
+        relax(c, it); it.s = push(it, rowval(k, j, X[k])); it.vL = 1.0; it.i0 = 0; it.i1 = 1;
+        if (gen()) { it.i2 = 2; it.i3 = 3; }
       }
     }
     mu = c.mu_init; tau = std::max(o.tau_min, 1.0 - mu);
@@ -438,8 +465,8 @@ struct Solver {
       for (int i = 0; i < NU; ++i) if (rR[k][i].on) { rR[k][i].r = (U[k][i] - U[k - 1][i]) - rR[k][i].s; theta += std::fabs(rR[k][i].r); }
       for (int j = 0; j < nobs; ++j) if (rO[k][j].on) {
         Ineq& it = rO[k][j]; const ObsP& q = obs[k][j];
-        it.r = hval(k, j, X[k]) - it.s; theta += std::fabs(it.r);
-        it.g0 = 2 * (X[k][0] - q.ox) * q.ix2; it.g1 = 2 * (X[k][1] - q.oy) * q.iy2;
+        it.r = rowval(k, j, X[k]) - it.s; theta += std::fabs(it.r);
+        (void)q; row_derivs(k, j, X[k], it);
       }
     }
     fval = objective(X, U);
@@ -482,7 +509,7 @@ struct Solver {
           if (idx < nx) rX[idx] -= y * gg;
           else if (idx >= na) rU[idx - na] -= y * gg;      // Uprev part is accounted at stage k-1 above
         };
-        add(it.i0, it.g0); add(it.i1, it.g1);
+        for (int a = 0; a < 4; ++a) add(it.idx(a), it.gv(a));
         if (it.hasL) { e.comp = std::max(e.comp, std::fabs((it.s - it.L) * it.vL - mu_)); sum_v += it.vL; ++n_v; }
         if (it.hasU) { e.comp = std::max(e.comp, std::fabs((it.U - it.s) * it.vU - mu_)); sum_v += it.vU; ++n_v; }
         e.prim = std::max(e.prim, std::fabs(it.r));
@@ -522,13 +549,13 @@ struct Solver {
       double sig = 0;
       if (it.hasL) sig += it.vL / (it.s - it.L);
       if (it.hasU) sig += it.vU / (it.U - it.s);
-      int id[2] = {it.i0, it.i1}; double gg[2] = {it.g0, it.g1};
-      for (int a = 0; a < 2; ++a) if (id[a] >= 0)
-        for (int b = 0; b < 2; ++b) if (id[b] >= 0) Hk[id[a]][id[b]] += sig * gg[a] * gg[b];
+      for (int a = 0; a < 4; ++a) if (it.idx(a) >= 0)
+        for (int b = 0; b < 4; ++b) if (it.idx(b) >= 0) Hk[it.idx(a)][it.idx(b)] += sig * it.gv(a) * it.gv(b);
     });
     if (k >= 1 && obs_node[k]) for (int j = 0; j < nobs; ++j) if (rO[k][j].on) {   // - y * d2h
       double y = rO[k][j].y();
-      Hk[0][0] -= y * 2 * obs[k][j].ix2; Hk[1][1] -= y * 2 * obs[k][j].iy2;
+      if (gen()) { for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) Hk[a][b] -= y * rO[k][j].hc[a][b]; }
+      else { Hk[0][0] -= y * 2 * obs[k][j].ix2; Hk[1][1] -= y * 2 * obs[k][j].iy2; }
     }
     if (k >= 1) for (int i = 0; i < nx; ++i) Hk[i][i] += dw;
     if (k < N) for (int i = 0; i < NU; ++i) Hk[na + i][na + i] += dw;
@@ -552,8 +579,7 @@ struct Solver {
       if (it.hasL) { sig += it.vL / (it.s - it.L); gb += it.tL / (it.s - it.L); }
       if (it.hasU) { sig += it.vU / (it.U - it.s); gb -= it.tU / (it.U - it.s); }
       gb -= sig * it.r;
-      if (it.i0 >= 0) gk[it.i0] -= gb * it.g0;
-      if (it.i1 >= 0) gk[it.i1] -= gb * it.g1;
+      for (int a = 0; a < 4; ++a) if (it.idx(a) >= 0) gk[it.idx(a)] -= gb * it.gv(a);
     });
   }
 
@@ -631,7 +657,7 @@ struct Solver {
         if (idx < na) return k ? dU[k - 1][idx - nx] : 0.0;
         return dU[k][idx - na];
       };
-      it.ds = it.g0 * comp(it.i0) + it.g1 * comp(it.i1) + it.r;
+      it.ds = it.g0 * comp(it.i0) + it.g1 * comp(it.i1) + it.g2 * comp(it.i2) + it.g3 * comp(it.i3) + it.r;
       if (it.hasL) { double d = it.s - it.L; it.dvL = it.tL / d - it.vL - it.vL / d * it.ds; }
       if (it.hasU) { double d = it.U - it.s; it.dvU = it.tU / d - it.vU + it.vU / d * it.ds; }
     });
@@ -684,7 +710,7 @@ struct Solver {
       }
       if (k >= 1 && obs_node[k]) for (int j = 0; j < nobs; ++j) if (rO[k][j].on) {
         double s = rO[k][j].s + alpha * rO[k][j].ds; bar(rO[k][j], s);
-        t.theta += std::fabs(hval(k, j, Xt[k]) - s);
+        t.theta += std::fabs(rowval(k, j, Xt[k]) - s);
       }
     }
     t.phi = phi;
@@ -919,8 +945,17 @@ struct Solver {
       for (int k = 1; k < N; ++k) { int q = 0; for (int i = 0; i < NU; ++i) if (rR[k][i].on) lam_g[rate_row[k] + q++] = -rR[k][i].y() / os; }
       const int last_row = c.obs_terminal ? N : N - 1;
       for (int i = 0; i <= last_row; ++i) {
-        int k = (c.obs_mode == MPCB_OBS_KEEPOUT) ? i : i + 1;
+        int k = (c.obs_mode == MPCB_OBS_KEEPOUT || gen()) ? i : i + 1;
         for (int j = 0; j < nobs; ++j) if (k >= 1 && k <= N && rO[k][j].on) lam_g[r + i * nobs + j] = -rO[k][j].y() / os;
+      }
+      // general-gamma rows were solved as c_i(X_i) = h(F(X_i)) - (1-gamma) h(X_i); in the reference's form the same row is
+      // h(X_{i+1}) - (1-gamma) h(X_i) and its dependence on X_{i+1} moves  lam_c,i * grad h(X_{i+1})  into the multiplier of the
+      // dynamics row that defines X_{i+1}
+      if (gen()) for (int k = 1; k <= N - 1; ++k) for (int j = 0; j < nobs; ++j) if (rO[k][j].on) {
+        const ObsP& q = obs[k][j];
+        const double lc = -rO[k][j].y() / os;
+        lam_g[dyn_row[k + 1] + 0] -= lc * 2 * (X[k + 1][0] - q.ox) * q.ix2;
+        lam_g[dyn_row[k + 1] + 1] -= lc * 2 * (X[k + 1][1] - q.oy) * q.iy2;
       }
     }
   }
@@ -931,7 +966,8 @@ int check_cfg(const mpcb_config* c) {
   if (c->model != MPCB_MODEL_KIN && c->model != MPCB_MODEL_DYN) return MPCB_E_INVALID;
   if (c->N < 1 || c->N > MPCB_N_MAX || c->n_obs < 0 || c->n_obs > MPCB_NOBS_MAX) return MPCB_E_INVALID;
   if (!(c->T > 0) || !(c->tol > 0) || c->max_iter < 0) return MPCB_E_INVALID;
-  if (c->obs_mode == MPCB_OBS_DCBF && std::fabs(c->gamma - 1.0) > 1e-12) return MPCB_E_UNSUPPORTED;
+  if (c->obs_mode == MPCB_OBS_DCBF && !(c->gamma > 0.0 && c->gamma <= 1.0 + 1e-12)) return MPCB_E_INVALID;
+  if (c->obs_mode == MPCB_OBS_DCBF && c->gamma < 1.0 - 1e-12 && (c->model != MPCB_MODEL_KIN || c->obs_terminal)) return MPCB_E_UNSUPPORTED;
   return MPCB_OK;
 }
 
