@@ -54,7 +54,7 @@ extern "C" {
 
 /* obstacle rows */
 #define MPCB_OBS_KEEPOUT 0    /* h_j(X_i) >= 0, the shipped form          CMOM/MPC_CBF_optimize_kin.py:247 */
-#define MPCB_OBS_DCBF    1    /* gamma*h + (h_next - h) >= 0, commented   CMOM/MPC_CBF_optimize_kin.py:248 */
+#define MPCB_OBS_DCBF    1    /* gamma*h_i(X_i) + h_i(X_{i+1}) - h_i(X_i) >= 0, the commented form   kin.py:245-248 */
 
 /* barrier-parameter strategies */
 #define MPCB_MU_MONOTONE 0    /* IPOPT default: Fiacco-McCormick, mu_init = 0.1, kappa_mu = 0.2, theta_mu = 1.5 */
@@ -84,7 +84,7 @@ typedef struct mpcb_config {
   int32_t  init_rollout;      /* 0: take the X part of the start as given (what IPOPT receives);
                                  1: keep U of the start, roll X out from x0 with the model (multiple-shooting warm start) */
   double   T;                 /* T_S */
-  double   gamma;             /* DCBF gamma (kin.py:235) */
+  double   gamma;             /* DCBF gamma in (0, 1] (kin.py:235 sets 1.0); < 1: kinematic model only, rows i = 0..N-1 */
   double   Q[MPCB_NX_MAX];    /* diag of Q                                kin.py:168-172 */
   double   R[MPCB_NU];        /* diag of R                                kin.py:179-181 */
   double   DR[MPCB_NU];       /* diag of DR                               kin.py:182-184 */

@@ -55,12 +55,15 @@ def nlp_constraints(cfg, z, x0, obs, obs_kind):
         o = np.asarray(obs, dtype=np.float64).reshape(-1)
         last = N if cfg.obs_terminal else N - 1
         for i in range(last + 1):
-            node = i if cfg.obs_mode == _abi.OBS_KEEPOUT else i + 1
             for j in range(cfg.n_obs):
                 q = o[(j * (N + 1) + i) * 6:(j * (N + 1) + i) * 6 + 6] if obs_kind == _abi.OBSIN_PREDICTED else o[j * 6:j * 6 + 6]
                 sx = cfg.obs_sx_fixed if cfg.obs_sx_fixed > 0 else cfg.ego_hl + q[4] / 2 + cfg.safe_disl
                 sy = cfg.obs_sy_fixed if cfg.obs_sy_fixed > 0 else cfg.ego_hw + q[5] / 2 + cfg.safe_disw
-                rows.append(np.array([(X[node, 0] - q[0]) ** 2 / sx ** 2 + (X[node, 1] - q[1]) ** 2 / sy ** 2 - 1.0]))
+                h = lambda node: (X[node, 0] - q[0]) ** 2 / sx ** 2 + (X[node, 1] - q[1]) ** 2 / sy ** 2 - 1.0   # noqa: E731
+                if cfg.obs_mode == _abi.OBS_KEEPOUT:
+                    rows.append(np.array([h(i)]))                                        # kin.py:247
+                else:                                                                     # kin.py:245-248: gamma h_i + (h_next - h_i)
+                    rows.append(np.array([h(i + 1) - (1.0 - cfg.gamma) * h(i)]))
     return np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1) for r in rows])
 
 
@@ -141,6 +144,10 @@ class MpcBase:
         self.num_controls = 2
         self.last_stats = {}
         self._solvers = {}
+        # The reference ships the keep-out rows `g.append(h_func)` and keeps the CBF rows `gamma*h_func + h_dot` commented
+        # next to them with `gamma = 1.00` (kin.py:235,247-248).  Same switch here: cbf_rows = True selects the commented form.
+        self.cbf_rows = False
+        self.gamma = 1.0
         self.f = ModelFunction(self._make_cfg(0))
 
     # ----- configuration of the HIP library from the YAML values ------------------------------------------
@@ -155,13 +162,15 @@ class MpcBase:
         c.ego_hl, c.ego_hw = self.Veh_L / 2, self.Veh_W / 2
         c.veh_m, c.veh_lf, c.veh_lr, c.veh_Iz = self.Veh_m, self.Veh_lf, self.Veh_lr, self.Veh_Iz
         c.Fymax_f, c.Fymax_r, c.aopt_f, c.aopt_r = self.Fymax_f, self.Fymax_r, self.aopt_f, self.aopt_r
+        if getattr(self, "cbf_rows", False) and self.MODEL == _abi.MODEL_KIN:
+            c.obs_mode, c.gamma = _abi.OBS_DCBF, float(self.gamma)
         if self.MODEL == _abi.MODEL_DYN:
             c.x_lo[4], c.x_hi[4] = self.vy_min, self.vy_max
             c.du_lo[1], c.du_hi[1] = self.jerk_min * self.T_S, self.jerk_max * self.T_S
         return c
 
     def _batch_solver(self, cfg):
-        key = (cfg.model, cfg.N, cfg.n_obs, cfg.obs_mode)
+        key = (cfg.model, cfg.N, cfg.n_obs, cfg.obs_mode, cfg.gamma)
         bs = self._solvers.get(key)
         if bs is None:
             bs = BatchSolver(cfg)

@@ -23,10 +23,10 @@ namespace {
 constexpr double INF = std::numeric_limits<double>::infinity();
 thread_local std::string g_create_error;
 
-template <int NOBS>
+template <int NOBS, bool GEN = false>
 __global__ __launch_bounds__(64, MPCB_WAVES_PER_SIMD) void mpcb_kernel_kin(const MpcbKArgs a) {
   extern __shared__ __attribute__((aligned(16))) double mpcb_lds[];
-  mpcb_solve_kin<NOBS>(a, (int)blockIdx.x, mpcb_lds);
+  mpcb_solve_kin<NOBS, GEN>(a, (int)blockIdx.x, mpcb_lds);
 }
 
 template <int NOBS>
@@ -120,8 +120,10 @@ int check_cfg(mpcb_handle* h, const mpcb_config* c) {
   if (!(c->T > 0) || !(c->tol > 0) || c->max_iter < 0 || !(c->mu_init > 0)) return fail(h, MPCB_E_INVALID, "T, tol, mu_init must be > 0 and max_iter >= 0");
   if (!(c->veh_l > 0)) return fail(h, MPCB_E_INVALID, "veh_l must be > 0");
   for (int i = 0; i < 2; ++i) if (!(c->R[i] > 0)) return fail(h, MPCB_E_INVALID, "R must be positive");
-  if (c->obs_mode == MPCB_OBS_DCBF && std::fabs(c->gamma - 1.0) > 1e-12)
-    return fail(h, MPCB_E_UNSUPPORTED, "discrete-CBF rows are implemented for gamma = 1 only (the reference's value, kin.py:235)");
+  if (c->obs_mode == MPCB_OBS_DCBF && !(c->gamma > 0.0 && c->gamma <= 1.0 + 1e-12))
+    return fail(h, MPCB_E_INVALID, "discrete-CBF rows need 0 < gamma <= 1 (kin.py:235 uses 1.0), got %g", c->gamma);
+  if (c->obs_mode == MPCB_OBS_DCBF && c->gamma < 1.0 - 1e-12 && (c->model != MPCB_MODEL_KIN || c->obs_terminal))
+    return fail(h, MPCB_E_UNSUPPORTED, "general-gamma discrete-CBF rows are implemented for the kinematic model with rows i = 0..N-1");
   if (c->obs_mode != MPCB_OBS_KEEPOUT && c->obs_mode != MPCB_OBS_DCBF) return fail(h, MPCB_E_INVALID, "unknown obs_mode %d", c->obs_mode);
   if (c->mu_strategy != MPCB_MU_MONOTONE) return fail(h, MPCB_E_UNSUPPORTED, "only MPCB_MU_MONOTONE is implemented on the device");
   if (std::isfinite(c->x_lo[0]) || std::isfinite(c->x_hi[0]) || std::isfinite(c->x_lo[2]) || std::isfinite(c->x_hi[2]))
@@ -170,6 +172,17 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a) {
     else if (n <= 3) LAUNCH_DYN(3);
     else if (n <= 5) LAUNCH_DYN(5);
     else LAUNCH_DYN(8);
+  } else if (h->cfg.obs_mode == MPCB_OBS_DCBF && h->cfg.gamma < 1.0 - 1e-12 && n > 0) {   // general-gamma CBF rows
+#define LAUNCH_GEN(NOBS)                                                                                       \
+  do {                                                                                                         \
+    if (lds > 48 * 1024)                                                                                       \
+      HIP_TRY(h, hipFuncSetAttribute((const void*)mpcb_kernel_kin<NOBS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((mpcb_kernel_kin<NOBS, true>), grid, block, lds, h->stream, a);                         \
+  } while (0)
+    if (n == 1) LAUNCH_GEN(1);
+    else if (n <= 3) LAUNCH_GEN(3);
+    else LAUNCH_GEN(8);
+#undef LAUNCH_GEN
   } else if (n == 0) LAUNCH(0);
   else if (n == 1) LAUNCH(1);
   else if (n <= 3) LAUNCH(3);

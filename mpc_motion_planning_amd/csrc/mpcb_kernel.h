@@ -63,6 +63,7 @@ enum KinEnt {
   E_D0, E_D1, E_D2, E_D3,                               // dynamics defect F_k - X_{k+1}
   E_G0, E_G1, E_G2, E_G3, E_G4, E_G5, E_G6, E_G7,       // condensed gradient
   E_HXX, E_HXY, E_HYY, E_HPP, E_HPV, E_HVV, E_HVD, E_HDD, E_HAA, E_H44, E_H55, E_H46, E_H57,
+  E_HXP, E_HXV, E_HYP, E_HYV,                           // only non-zero with general-gamma CBF rows (GEN kernels)
   KIN_NENT
 };
 
@@ -162,7 +163,11 @@ constexpr double DW_FIRST = 1e-4, DW_MIN = 1e-20, DW_MAX = 1e40, KW_MINUS = 1.0 
 // =============================================================================================================
 // Kinematic bicycle, NOBS = compile-time capacity of obstacle rows per node (cfg.n_obs <= NOBS at run time).
 // =============================================================================================================
-template <int NOBS>
+// GEN = general-gamma discrete-CBF rows (kin.py:245-248 with 0 < gamma < 1): row i is solved as the STATE constraint of node i
+//   c_i(X_i) = h(X_i + T f(X_i)) - (1 - gamma) h(X_i) >= gamma hmin      (stage-i obstacle in both terms, as the reference writes it)
+// which equals the reference's  gamma h(X_i) + h(X_{i+1}) - h(X_i)  on the feasible set because the position part of the Euler
+// step depends on X_i only.  Its gradient has four entries (x, y, phi, v) and its Hessian fills the state block.
+template <int NOBS, bool GEN = false>
 MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   using namespace mpcbk;
   constexpr int NX = 4, NA = 6, NW = 8, NOB = NOBS > 0 ? NOBS : 1;
@@ -185,6 +190,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   const int last_row = c.obs_terminal ? N : N - 1;
   bool obs_node; int ostep;
   if (c.obs_mode == MPCB_OBS_KEEPOUT) { obs_node = k <= last_row; ostep = k; }
+  else if (GEN) { obs_node = k <= N - 1; ostep = k; }
   else { obs_node = k >= 1 && k - 1 <= last_row; ostep = k - 1; }
   obs_node = obs_node && isnode;
   double ox[NOB], oy[NOB], ix2[NOB], iy2[NOB];
@@ -203,6 +209,12 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   auto hval = [&](int j, double px, double py) {
     double dx = px - ox[j], dy = py - oy[j];
     return dx * dx * ix2[j] + dy * dy * iy2[j] - 1.0;
+  };
+  const double omg = GEN ? 1.0 - c.gamma : 0.0;                     // (1 - gamma) of the general CBF row
+  // value of obstacle row j at a node with position (px,py), heading sin/cos (s_,c_) and speed v
+  auto rowval = [&](int j, double px, double py, double s_, double c_, double v) {
+    if (!GEN) return hval(j, px, py);
+    return hval(j, px + T * (v * c_), py + T * (v * s_)) - omg * hval(j, px, py);
   };
 
   // ----- start point: z0 row (coalesced) -> LDS -> node lanes ---------------------------------------------------
@@ -261,7 +273,11 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       for (int i = 0; i < NX; ++i) bad = bad || (X[i] < c.x_lo[i] - 1e-8) || (X[i] > c.x_hi[i] + 1e-8);
       if (obs_node) {
 #pragma unroll
-        for (int j = 0; j < NOBS; ++j) if (j < nobs) bad = bad || (hval(j, X[0], X[1]) < c.obs_hmin - 1e-8);
+        for (int j = 0; j < NOBS; ++j) if (j < nobs) {
+          double s0 = 0, c0 = 1;
+          if (GEN) sincos_b(X[2], s0, c0);
+          bad = bad || (rowval(j, X[0], X[1], s0, c0, X[3]) < (GEN ? c.gamma : 1.0) * c.obs_hmin - 1e-8);
+        }
       }
     }
     if (wv::any(bad)) status = MPCB_ST_INFEASIBLE_X0;
@@ -271,7 +287,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   const Bnd qU0 = mk_bnd(c.u_lo[0], c.u_hi[0], c.bound_relax), qU1 = mk_bnd(c.u_lo[1], c.u_hi[1], c.bound_relax);
   const Bnd qY = mk_bnd(c.x_lo[1], c.x_hi[1], c.bound_relax), qV = mk_bnd(c.x_lo[3], c.x_hi[3], c.bound_relax);
   const Bnd qR = mk_bnd(c.du_lo[0], c.du_hi[0], c.bound_relax);
-  const Bnd qO = mk_bnd(c.obs_hmin, 1e308, c.bound_relax);
+  const Bnd qO = mk_bnd((GEN ? c.gamma : 1.0) * c.obs_hmin, 1e308, c.bound_relax);
   const bool bu0_on = hasu && qU0.on, bu1_on = hasu && qU1.on, by_on = xnode && qY.on, bv_on = xnode && qV.on;
   const bool rr_on = xcost && qR.on;
   const bool ro_node = xnode && obs_node;
@@ -311,14 +327,33 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   double Up0 = wv::shfl(U[0], k - 1), Up1 = wv::shfl(U[1], k - 1);   // U_{k-1}
   double sR = 0, rR = 0;
   if (rr_on) sR = push_in(qR, U[0] - Up0, c.bound_push, c.bound_frac);
-  double sO[NOB], vO[NOB], iO[NOB], rO[NOB], gO0[NOB], gO1[NOB];
+  double sO[NOB], vO[NOB], iO[NOB], rO[NOB], gO0[NOB], gO1[NOB], gO2[GEN ? NOB : 1], gO3[GEN ? NOB : 1];
   bool ro_on[NOB];
+  {
+    double s0 = 0, c0 = 1;
+    if (GEN) sincos_b(X[2], s0, c0);
 #pragma unroll
-  for (int j = 0; j < NOBS; ++j) {
-    ro_on[j] = ro_node && j < nobs;
-    sO[j] = ro_on[j] ? push_in(qO, hval(j, X[0], X[1]), c.bound_push, c.bound_frac) : 1.0;
-    vO[j] = 1.0; rO[j] = 0; gO0[j] = 0; gO1[j] = 0; iO[j] = 0;
+    for (int j = 0; j < NOBS; ++j) {
+      ro_on[j] = ro_node && j < nobs;
+      sO[j] = ro_on[j] ? push_in(qO, rowval(j, X[0], X[1], s0, c0, X[3]), c.bound_push, c.bound_frac) : 1.0;
+      vO[j] = 1.0; rO[j] = 0; gO0[j] = 0; gO1[j] = 0; iO[j] = 0;
+      if (GEN) { gO2[j] = 0; gO3[j] = 0; }
+    }
   }
+  // gradient of the obstacle rows at the iterate (X, sp, cp)
+  auto row_grads = [&](double sp_, double cp_) {
+#pragma unroll
+    for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
+      const double dpx = 2 * (X[0] - ox[j]) * ix2[j], dpy = 2 * (X[1] - oy[j]) * iy2[j];
+      if (!GEN) { gO0[j] = dpx; gO1[j] = dpy; }
+      else {
+        const double v = X[3];
+        const double dqx = 2 * (X[0] + T * (v * cp_) - ox[j]) * ix2[j], dqy = 2 * (X[1] + T * (v * sp_) - oy[j]) * iy2[j];
+        gO0[j] = dqx - omg * dpx; gO1[j] = dqy - omg * dpy;
+        gO2[j] = T * v * (dqy * cp_ - dqx * sp_); gO3[j] = T * (dqx * cp_ + dqy * sp_);
+      }
+    }
+  };
   auto recips = [&]() {
     if (bu0_on) item_recip(qU0, U[0], iU0);
     if (bu1_on) item_recip(qU1, U[1], iU1);
@@ -355,7 +390,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     rRa = 0;
     if (rr_on) { bar(qR, sRa); rRa = (Ua[0] - up0) - sRa; th += fabs(rRa); }
 #pragma unroll
-    for (int j = 0; j < NOBS; ++j) { rOa[j] = 0; if (ro_on[j]) { bar(qO, sOa[j]); rOa[j] = hval(j, Xa[0], Xa[1]) - sOa[j]; th += fabs(rOa[j]); } }
+    for (int j = 0; j < NOBS; ++j) { rOa[j] = 0; if (ro_on[j]) { bar(qO, sOa[j]); rOa[j] = rowval(j, Xa[0], Xa[1], s_, c_, v) - sOa[j]; th += fabs(rOa[j]); } }
     if (hasu) {   // objective terms of stage k (kin.py:195-205)
 #pragma unroll
       for (int i = 0; i < NX; ++i) { const double e = Xa[i] - cst[CS_XS + i]; fl += cst[CS_Q + i] * e * e; }
@@ -418,6 +453,12 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     if (lo == 5 && hi == 5) return E_H55;
     if (lo == 4 && hi == 6) return E_H46;
     if (lo == 5 && hi == 7) return E_H57;
+    if (GEN) {
+      if (lo == 0 && hi == 2) return E_HXP;
+      if (lo == 0 && hi == 3) return E_HXV;
+      if (lo == 1 && hi == 2) return E_HYP;
+      if (lo == 1 && hi == 3) return E_HYV;
+    }
     return E_ZERO;
   };
   // Column 4 of the stage block belongs to U_prev, whose column of [A B] is zero: W(:,4) = 0 and M(:,4) = H(:,4) need no
@@ -475,8 +516,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       wv::reduce<3, 0>(sv, nullptr);
       theta = wv::uni(sv[0]); fval = wv::uni(sv[1]); logsum = wv::uni(sv[2]);
       recips();
-#pragma unroll
-      for (int j = 0; j < NOBS; ++j) if (ro_on[j]) { gO0[j] = 2 * (X[0] - ox[j]) * ix2[j]; gO1[j] = 2 * (X[1] - oy[j]) * iy2[j]; }
+      row_grads(sp, cp);
     }
     theta_max = wv::uni(1e4 * fmax(1.0, theta)); theta_min = wv::uni(1e-4 * fmax(1.0, theta));
 
@@ -529,6 +569,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
 #pragma unroll
         for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
           rX[0] -= vO[j] * gO0[j]; rX[1] -= vO[j] * gO1[j];
+          if (GEN) { rX[2] -= vO[j] * gO2[j]; rX[3] -= vO[j] * gO3[j]; }
           const double p = (sO[j] - qO.L) * vO[j]; svmax = fmax(svmax, p); svmin = fmin(svmin, p); sum_v += vO[j];
           prim = fmax(prim, fabs(rO[j]));
         }
@@ -570,6 +611,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
 
       // ----- condensed stage QP: lane k writes the compact entries of stage k ------------------------------------
       double hxx = 0, hxy = 0, hyy = 0, hpp = 0, hpv = 0, hvv = 0, hvd = 0, hdd = 0, haa = 0, h44 = 0, h55 = 0, h46 = 0, h57 = 0;
+      double hxp = 0, hxv = 0, hyp = 0, hyv = 0;      // GEN only
       {
         double g[NW] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (xcost) {
@@ -602,10 +644,28 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
 #pragma unroll
         for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
           sig = vO[j] * iO[j]; gb = mu * iO[j] - sig * rO[j];
-          hxx += sig * gO0[j] * gO0[j] - vO[j] * 2 * ix2[j];
-          hxy += sig * gO0[j] * gO1[j];
-          hyy += sig * gO1[j] * gO1[j] - vO[j] * 2 * iy2[j];
-          g[0] -= gb * gO0[j]; g[1] -= gb * gO1[j];
+          if (!GEN) {
+            hxx += sig * gO0[j] * gO0[j] - vO[j] * 2 * ix2[j];
+            hxy += sig * gO0[j] * gO1[j];
+            hyy += sig * gO1[j] * gO1[j] - vO[j] * 2 * iy2[j];
+            g[0] -= gb * gO0[j]; g[1] -= gb * gO1[j];
+          } else {
+            // sig g g^T - v d2c, c = h(q) - (1-gamma) h(p), q = p + T v (cos phi, sin phi)
+            const double v = X[3], y = vO[j], Tv = T * v;
+            const double dqx = 2 * (X[0] + Tv * cp - ox[j]) * ix2[j], dqy = 2 * (X[1] + Tv * sp - oy[j]) * iy2[j];
+            const double g0 = gO0[j], g1 = gO1[j], g2 = gO2[j], g3 = gO3[j];
+            hxx += sig * g0 * g0 - y * (2 * c.gamma * ix2[j]);
+            hxy += sig * g0 * g1;
+            hyy += sig * g1 * g1 - y * (2 * c.gamma * iy2[j]);
+            hxp += sig * g0 * g2 - y * (-2 * ix2[j] * Tv * sp);
+            hxv += sig * g0 * g3 - y * (2 * ix2[j] * T * cp);
+            hyp += sig * g1 * g2 - y * (2 * iy2[j] * Tv * cp);
+            hyv += sig * g1 * g3 - y * (2 * iy2[j] * T * sp);
+            hpp += sig * g2 * g2 - y * (2 * Tv * Tv * (ix2[j] * sp * sp + iy2[j] * cp * cp) - Tv * (dqx * cp + dqy * sp));
+            hpv += sig * g2 * g3 - y * (T * (dqy * cp - dqx * sp) + 2 * T * Tv * sp * cp * (iy2[j] - ix2[j]));
+            hvv += sig * g3 * g3 - y * (2 * T * T * (ix2[j] * cp * cp + iy2[j] * sp * sp));
+            g[0] -= gb * g0; g[1] -= gb * g1; g[2] -= gb * g2; g[3] -= gb * g3;
+          }
         }
         if (isnode) {
           ent[E_A02 * ld + k] = hasu ? a02 : 0.0; ent[E_A03 * ld + k] = hasu ? a03 : 0.0;
@@ -623,6 +683,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           Pst[k * PST + PS_ZERO] = 0.0;
           ent[E_HXY * ld + k] = hxy; ent[E_HPV * ld + k] = hpv; ent[E_HVD * ld + k] = hvd;
           ent[E_H44 * ld + k] = h44; ent[E_H55 * ld + k] = h55; ent[E_H46 * ld + k] = h46; ent[E_H57 * ld + k] = h57;
+          if (GEN) { ent[E_HXP * ld + k] = hxp; ent[E_HXV * ld + k] = hxv; ent[E_HYP * ld + k] = hyp; ent[E_HYV * ld + k] = hyv; }
         }
       }
 
@@ -796,7 +857,10 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       const double dsR = rr_on ? (dU[0] - dUp0) + rR : 0.0;
       double dsO[NOB];
 #pragma unroll
-      for (int j = 0; j < NOBS; ++j) dsO[j] = ro_on[j] ? gO0[j] * dX[0] + gO1[j] * dX[1] + rO[j] : 0.0;
+      for (int j = 0; j < NOBS; ++j) {
+        dsO[j] = ro_on[j] ? gO0[j] * dX[0] + gO1[j] * dX[1] + rO[j] : 0.0;
+        if (GEN && ro_on[j]) dsO[j] += gO2[j] * dX[2] + gO3[j] * dX[3];
+      }
 
       // ----- fraction to the boundary (as the largest step ratios) and d(barrier function) along the step --------
       double a_pr, a_du, dphi;
@@ -928,10 +992,8 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) dfc[i] = dft[i];
 #pragma unroll
-      for (int j = 0; j < NOBS; ++j) {
-        sO[j] = sOt[j]; rO[j] = rOt[j];
-        if (ro_on[j]) { gO0[j] = 2 * (X[0] - ox[j]) * ix2[j]; gO1[j] = 2 * (X[1] - oy[j]) * iy2[j]; }
-      }
+      for (int j = 0; j < NOBS; ++j) { sO[j] = sOt[j]; rO[j] = rOt[j]; }
+      row_grads(sp, cp);
       theta = tht; fval = ft; logsum = lst;
       if (!isfinite(theta) || !isfinite(fval)) { status = MPCB_ST_NUMERIC; break; }
     }
@@ -980,9 +1042,20 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     double ln[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) ln[i] = wv::shfl(lam[i], k + 1);
+    double cx = 0, cy = 0;
+    if (GEN) {
+      // the general-gamma row of node k-1 reads h(X_k) in the reference's form: its multiplier times grad h(X_k) belongs to
+      // the dynamics row that defines X_k (lam_c = -v / os, so the correction is + v / os * grad h)
+#pragma unroll
+      for (int j = 0; j < NOBS; ++j) {
+        const double vp = wv::shfl(ro_on[j] ? vO[j] : 0.0, k - 1);
+        const double oxp = wv::shfl(ox[j], k - 1), oyp = wv::shfl(oy[j], k - 1), ixp = wv::shfl(ix2[j], k - 1), iyp = wv::shfl(iy2[j], k - 1);
+        if (k >= 2) { cx += vp * 2 * (X[0] - oxp) * ixp; cy += vp * 2 * (X[1] - oyp) * iyp; }
+      }
+    }
     if (xnode) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) out[r_dyn + NX * (k - 1) + i] = -lam[i] / os;
+      for (int i = 0; i < NX; ++i) out[r_dyn + NX * (k - 1) + i] = (-lam[i] + (i == 0 ? cx : i == 1 ? cy : 0.0)) / os;
     }
     if (k == 0) {   // stationarity wrt the pinned X_0
       const double a02 = -T * X[3] * sp, a03 = T * cp, a12 = T * X[3] * cp, a13 = T * sp, a23 = T * td * il;
@@ -992,7 +1065,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     }
     if (rr_on) out[r_rate + (k - 1)] = -item_y(qR, iR) / os;
     if (isnode) {
-      const int row = (c.obs_mode == MPCB_OBS_KEEPOUT) ? k : k - 1;
+      const int row = (c.obs_mode == MPCB_OBS_KEEPOUT || GEN) ? k : k - 1;
 #pragma unroll
       for (int j = 0; j < NOBS; ++j) if (j < nobs && row >= 0 && row <= last_row) out[r_obs + row * nobs + j] = ro_on[j] ? -vO[j] / os : 0.0;
     }

@@ -28,7 +28,10 @@ static void run_instance(const MpcbKArgs& a, int b) {
   for (int l = 0; l < 64; ++l)
     th.emplace_back([&, l]() {
       wv::t_lane = l; wv::t_emu = &emu;
-      if (dyn) mpcb_solve_dyn<NOBS>(a, b, lds.data()); else mpcb_solve_kin<NOBS>(a, b, lds.data());
+      const bool gen = !dyn && a.cfg.obs_mode == MPCB_OBS_DCBF && a.cfg.gamma < 1.0 - 1e-12 && NOBS > 0;   // as mpcb_api.hip dispatches
+      if (dyn) mpcb_solve_dyn<NOBS>(a, b, lds.data());
+      else if (gen) mpcb_solve_kin<(NOBS > 0 ? NOBS : 1), true>(a, b, lds.data());
+      else mpcb_solve_kin<NOBS>(a, b, lds.data());
     });
   for (auto& t : th) t.join();
 }

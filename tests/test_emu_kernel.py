@@ -46,6 +46,16 @@ def test_emulated_kernel_variants():
     assert e["status"][0] == 0 and np.abs(e["z"] - r["z"]).max() <= 1e-8 and np.abs(e["lam_g"] - r["lam_g"]).max() <= 1e-5 * np.abs(r["lam_g"]).max()
 
 
+def test_emulated_kernel_general_gamma_cbf_rows():
+    """GEN kernels (0 < gamma < 1): closed-form gradient and Hessian of c_i(X_i) = h(F(X_i)) - (1-gamma) h(X_i) against the
+    oracle's AD, multipliers converted to the reference's row form."""
+    c = product_cfg(30, 1); c.obs_mode = _abi.OBS_DCBF; c.gamma = 0.5
+    e = emu.solve(c, G["S_x0"], G["S_xs"], G["S_obs"]); r = oracle.solve(c, G["S_x0"], G["S_xs"], G["S_obs"])
+    assert e["status"][0] == r["status"][0] == 0 and e["iters"][0] == r["iters"][0]
+    assert np.abs(e["z"] - r["z"]).max() <= 1e-9
+    assert np.abs(e["lam_g"] - r["lam_g"]).max() <= 1e-8 * np.abs(r["lam_g"]).max()
+
+
 def test_emulated_kernel_failure_paths():
     c = product_cfg()
     e = emu.solve(c, [[48.0, 3.5, 0, 10]], G["S_xs"], G["S_obs"])

@@ -117,9 +117,10 @@ def test_edge_cases_on_device(gpu_solver_factory):
     assert r["z"].shape == (0, 184)
     r = bs.solve_batch([[48.0, 3.5, 0, 10], [0.0, 6.0, 0, 10], [40.0, 3.5, 0, 25]], np.tile(scenes.SHIPPED_XS, (3, 1)), np.tile(scenes.SHIPPED_OBS, (3, 1, 1)))
     assert list(r["status"][:2]) == [_abi.ST_INFEASIBLE_X0] * 2 and r["status"][2] != 0 and np.all(np.isfinite(r["z"]))
-    with pytest.raises(MpcbError):
-        bad = default_config(N=30, n_obs=1); bad.obs_mode = _abi.OBS_DCBF; bad.gamma = 0.8
-        gpu_solver_factory(bad)
+    for gamma, model in ((1.5, _abi.MODEL_KIN), (0.0, _abi.MODEL_KIN), (0.8, _abi.MODEL_DYN)):
+        with pytest.raises(MpcbError):     # gamma outside (0, 1]; general gamma for the dyn model (not implemented)
+            bad = default_config(model=model, N=30, n_obs=1); bad.obs_mode = _abi.OBS_DCBF; bad.gamma = gamma
+            gpu_solver_factory(bad)
     with pytest.raises(ValueError):
         bs.solve_batch(np.zeros((2, 3)), np.zeros((2, 4)), np.zeros((2, 1, 6)))
     # mis-aligned bounds are rejected (the defect pattern of MPC_CBF_optimize_dyn.py:112-129)
@@ -362,3 +363,23 @@ def test_fuzzed_structures_against_oracle(gpu_solver_factory):
     spec = importlib.util.spec_from_file_location("fuzz_gpu_vs_oracle", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_gpu_vs_oracle.py"))
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     assert mod.run(cases=40, seed=11, verbose=False) == 0
+
+
+@pytest.mark.parametrize("n_obs,gamma", [(1, 0.8), (3, 0.5), (5, 0.3)])
+def test_general_gamma_cbf_rows(gpu_solver_factory, oracle_mod, n_obs, gamma):
+    """General-gamma discrete-CBF rows (kin.py:245-248 with 0 < gamma < 1; GEN kernels kin<1|3|8, true>): trajectories,
+    multipliers in the reference's row form and objective against the oracle; the shipped scene also against the KKT
+    certificate of the reference-form NLP."""
+    cfg = default_config(N=30, n_obs=n_obs); cfg.obs_mode = _abi.OBS_DCBF; cfg.gamma = gamma
+    x0, xs, _, traj = scenes.sample_c3(96, N=30, dt=0.1, seed=300 + n_obs, n_obs=n_obs)
+    g = gpu_solver_factory(cfg).solve_batch(x0, xs, traj, multipliers=True); r = oracle_mod.solve(cfg, x0, xs, traj)
+    both = agree(g, r, min_same_status=0.95)
+    sc = np.maximum(1.0, np.abs(r["lam_g"][both]).max(axis=1, keepdims=True))
+    assert (np.abs(g["lam_g"][both] - r["lam_g"][both]) / sc).max() <= 1e-4
+    assert np.abs(g["obj"][both] / r["obj"][both] - 1).max() <= 1e-8
+    if n_obs == 1:
+        from oracle import kkt_check
+        s = gpu_solver_factory(cfg).solve_batch(G["S_x0"], G["S_xs"], G["S_obs"], multipliers=True)
+        nlp = kkt_check.KinNlp(30, 0.1, scenes.SHIPPED_X0, scenes.SHIPPED_XS, scenes.SHIPPED_OBS, obs_mode="dcbf", gamma=gamma)
+        c = kkt_check.certificate(nlp, s["z"][0], s["lam_g"][0], s["lam_x"][0])
+        assert s["status"][0] == 0 and c["stationarity"] <= 1e-6 * c["lam_scale"] and c["feas_g"] <= 2e-8 and c["sign"] == 0.0

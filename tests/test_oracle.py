@@ -106,6 +106,22 @@ def test_edge_cases():
     nlp = kkt_check.KinNlp(30, 0.1, scenes.SHIPPED_X0, scenes.SHIPPED_XS, scenes.SHIPPED_OBS, obs_mode="dcbf", gamma=1.0)
     cert = kkt_check.certificate(nlp, r["z"][0], r["lam_g"][0], r["lam_x"][0])
     assert cert["stationarity"] <= 1e-6 * cert["lam_scale"] and cert["feas_g"] <= 2e-8
+    # general gamma (kin.py:245-248 with 0 < gamma < 1): the solver works on c_i(X_i) = h(F(X_i)) - (1-gamma) h(X_i); the
+    # certificate judges its point AND its multipliers on the reference's own form  gamma h_i + h_next - h_i  (two obstacles,
+    # predicted positions)
+    ob = np.array([[50, 3.5, 0, 8, 4.8, 1.8], [90, 0.0, 0, 6, 4.8, 1.8]])
+    traj = scenes.predict_obstacles(ob, 0.1, 30)
+    for gamma in (0.6, 0.25):
+        c = product_cfg(30, 2); c.obs_mode = _abi.OBS_DCBF; c.gamma = gamma
+        r = oracle.solve(c, scenes.SHIPPED_X0[None], xs, traj[None])
+        assert r["status"][0] == 0
+        nlp = kkt_check.KinNlp(30, 0.1, scenes.SHIPPED_X0, scenes.SHIPPED_XS, traj, obs_mode="dcbf", gamma=gamma)
+        cert = kkt_check.certificate(nlp, r["z"][0], r["lam_g"][0], r["lam_x"][0])
+        assert cert["stationarity"] <= 1e-6 * cert["lam_scale"] and cert["feas_g"] <= 2e-8 and cert["sign"] == 0.0
+        assert nlp.g(r["z"][0])[-60:].min() >= -2e-8
+    bad = product_cfg(30, 1); bad.obs_mode = _abi.OBS_DCBF; bad.gamma = 1.5
+    with pytest.raises(Exception):
+        oracle.solve(bad, scenes.SHIPPED_X0[None], xs, scenes.SHIPPED_OBS[None])
 
 
 def test_hand_written_kinematic_derivatives_equal_ad():

@@ -88,3 +88,12 @@ def test_result_dict_constraint_values_follow_reference_row_order():
     g = nlp_constraints(cfg, z, x0, obs[None], _abi.OBSIN_STATIC)
     ref = kkt_check.KinNlp(30, 0.1, x0, [400, 3.5, 0, 30], obs, obs_mode="dcbf", gamma=1.0).g(z)
     assert np.abs(g - ref).max() <= 1e-12
+    cfg.gamma = 0.7                                                # general gamma: gamma h_i(X_i) + h_i(X_{i+1}) - h_i(X_i)
+    g = nlp_constraints(cfg, z, x0, obs[None], _abi.OBSIN_STATIC)
+    ref = kkt_check.KinNlp(30, 0.1, x0, [400, 3.5, 0, 30], obs, obs_mode="dcbf", gamma=0.7).g(z)
+    assert np.abs(g - ref).max() <= 1e-12
+    m.cbf_rows, m.gamma = True, 0.7                                # the switch on the drop-in class (kin.py:235,247-248)
+    c2 = m._make_cfg(2)
+    assert c2.obs_mode == _abi.OBS_DCBF and c2.gamma == 0.7
+    m.cbf_rows = False
+    assert m._make_cfg(2).obs_mode == _abi.OBS_KEEPOUT

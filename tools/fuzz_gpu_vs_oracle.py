@@ -34,14 +34,16 @@ def one_case(rng, c):
             obs = traj if kind == "predicted" else ob0
         if n_obs and rng.random() < 0.3:
             cfg.obs_mode = _abi.OBS_DCBF
-        if rng.random() < 0.2:
+            if rng.random() < 0.5:
+                cfg.gamma = float(rng.uniform(0.1, 0.95))      # general-gamma rows (GEN kernels)
+        if rng.random() < 0.2 and not (cfg.obs_mode == _abi.OBS_DCBF and cfg.gamma < 1.0):
             cfg.obs_terminal = 1
     if rng.random() < 0.2:
         cfg.tol = 1e-6
     if rng.random() < 0.2 and not dyn:          # dyn from z0 = 0 without the roll-out starts at vx = bound_push (1/vx in the tyre
         cfg.init_rollout = 0                     # model): both solvers fail there, in different ways
-    desc = "case %d: %s N=%d n_obs=%d(%s) B=%d mode=%d term=%d tol=%g rollout=%d" % (
-        c, "dyn" if dyn else "kin", N, n_obs, kind, B, cfg.obs_mode, cfg.obs_terminal, cfg.tol, cfg.init_rollout)
+    desc = "case %d: %s N=%d n_obs=%d(%s) B=%d mode=%d gamma=%.2f term=%d tol=%g rollout=%d" % (
+        c, "dyn" if dyn else "kin", N, n_obs, kind, B, cfg.obs_mode, cfg.gamma, cfg.obs_terminal, cfg.tol, cfg.init_rollout)
     try:
         bs = BatchSolver(cfg)
     except Exception as e:                       # configurations the library refuses are refused by design; show them
