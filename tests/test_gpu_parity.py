@@ -117,6 +117,11 @@ def test_edge_cases_on_device(gpu_solver_factory):
     assert r["z"].shape == (0, 184)
     r = bs.solve_batch([[48.0, 3.5, 0, 10], [0.0, 6.0, 0, 10], [40.0, 3.5, 0, 25]], np.tile(scenes.SHIPPED_XS, (3, 1)), np.tile(scenes.SHIPPED_OBS, (3, 1, 1)))
     assert list(r["status"][:2]) == [_abi.ST_INFEASIBLE_X0] * 2 and r["status"][2] != 0 and np.all(np.isfinite(r["z"]))
+    # non-finite inputs end with a failure status at iteration 0 (no hang, no effect on the neighbours in the batch)
+    xn = np.tile(scenes.SHIPPED_X0, (4, 1)); xn[0, 0] = np.nan; xn[1, 3] = np.inf; xn[2, 2] = np.nan
+    r = bs.solve_batch(xn, np.tile(scenes.SHIPPED_XS, (4, 1)), np.tile(scenes.SHIPPED_OBS, (4, 1, 1)))
+    assert all(s in (_abi.ST_INFEASIBLE_X0, _abi.ST_NUMERIC) for s in r["status"][:3]) and np.all(r["iters"][:3] == 0)
+    assert r["status"][3] == 0 and np.abs(r["z"][3] - G["S_z"][0]).max() <= TOL_Z
     for gamma, model in ((1.5, _abi.MODEL_KIN), (0.0, _abi.MODEL_KIN), (0.8, _abi.MODEL_DYN)):
         with pytest.raises(MpcbError):     # gamma outside (0, 1]; general gamma for the dyn model (not implemented)
             bad = default_config(model=model, N=30, n_obs=1); bad.obs_mode = _abi.OBS_DCBF; bad.gamma = gamma
