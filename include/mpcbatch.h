@@ -159,7 +159,8 @@ int mpcb_solve_device(mpcb_handle* h, int32_t B,
 
 /* Closed loop on the device: `steps` receding-horizon iterations of  solve -> apply U_0 with the plant
  * x0 <- x0 + T f(x0,U_0) -> shift warm start [-> advance obstacles]   (main_cbf_kin_c_sim.py:87-123,16-26;
- * main_cbf_kin_c_sim_pre.py:98-106).  Host pointers.
+ * main_cbf_kin_c_sim_pre.py:98-106; with model = MPCB_MODEL_DYN the loop of main_cbf_dyn_c_sim.py:75-108, plant = the dyn
+ * model's own right-hand side).  Host pointers.
  *   obs_state [B, n_obs, 6] in/out
  *   obs_motion  MPCB_OBSMOVE_STATIC    obstacles never move, rows use obs_state as is      (main_cbf_kin_c_sim.py:55,99)
  *               MPCB_OBSMOVE_PREDICTED constant-velocity obstacles (Obs_prediction.py:27-30): predicted over the horizon

@@ -35,27 +35,51 @@ __global__ __launch_bounds__(64, MPCB_WAVES_PER_SIMD) void mpcb_kernel_dyn(const
   mpcb_solve_dyn<NOBS>(a, (int)blockIdx.x, mpcb_lds);
 }
 
-// closed-loop helper: plant step with the first control, warm-start shift, obstacle advance.
+// f(x,u) of the configured model: the reference's `mpc_solver.f` (kin.py:153-159, dyn.py:156-177); host and device
+__host__ __device__ inline void model_rhs(const mpcb_config& c, const double* x, const double* u, double* xdot) {
+  if (c.model == MPCB_MODEL_KIN) {                       // kin.py:153-156
+    xdot[0] = x[3] * cos(x[2]);
+    xdot[1] = x[3] * sin(x[2]);
+    xdot[2] = x[3] * tan(u[0]) / c.veh_l;
+    xdot[3] = u[1];
+  } else {                                               // dyn.py:156-170
+    const double phi = x[2], vx = x[3], vy = x[4], r = x[5], df = u[0], ax = u[1];
+    const double af = df - (vy + c.veh_lf * r) / vx, ar = -(vy - c.veh_lr * r) / vx;
+    const double Cf = c.Fymax_f * 2 * c.aopt_f / (c.aopt_f * c.aopt_f + af * af);
+    const double Cr = c.Fymax_r * 2 * c.aopt_r / (c.aopt_r * c.aopt_r + ar * ar);
+    const double Fcf = -Cf * af, Fcr = -Cr * ar;
+    xdot[0] = vx * cos(phi) - vy * sin(phi);
+    xdot[1] = vx * sin(phi) + vy * cos(phi);
+    xdot[2] = r;
+    xdot[3] = ax + r * vy;
+    xdot[4] = -r * vx + 2.0 / c.veh_m * (Fcf * cos(df) + Fcr);
+    xdot[5] = 2.0 / c.veh_Iz * (c.veh_lf * Fcf - c.veh_lr * Fcr);
+  }
+}
+
+// closed-loop helper: plant step with the first control, warm-start shift, obstacle advance; either model.
 // one thread per instance (tiny, HBM-bound, runs between two solves of the closed loop)
-//   main_cbf_kin_c_sim.py:16-26 (shift_movement), main_cbf_kin_c_sim_pre.py:106 (obstacle advance)
-__global__ void mpcb_advance_kin(int B, int N, int nz, int n_obs, double T, double veh_l, const double* __restrict__ z,
-                                 double* __restrict__ x0, double* __restrict__ z0, double* __restrict__ obs,
-                                 double* __restrict__ x_hist, double* __restrict__ u_hist, int step, int steps, int move_obs) {
+//   main_cbf_kin_c_sim.py:16-26 / main_cbf_dyn_c_sim.py:15-25 (shift_movement), main_cbf_kin_c_sim_pre.py:106 (obstacle advance)
+__global__ void mpcb_advance(const mpcb_config c, int B, int nx, int nz, const double* __restrict__ z,
+                             double* __restrict__ x0, double* __restrict__ z0, double* __restrict__ obs,
+                             double* __restrict__ x_hist, double* __restrict__ u_hist, int step, int steps, int move_obs) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
+  const int N = c.N, n_obs = c.n_obs;
+  const double T = c.T;
   const double* zb = z + (size_t)b * nz;
-  double* xb = x0 + (size_t)b * 4;
-  const double d = zb[0], ac = zb[1];
-  const double x = xb[0], y = xb[1], phi = xb[2], v = xb[3];
-  // st = x0 + T f(x0, u[0])
-  const double nx0 = x + T * (v * cos(phi)), nx1 = y + T * (v * sin(phi)), nx2 = phi + T * (v * tan(d) / veh_l), nx3 = v + T * ac;
-  xb[0] = nx0; xb[1] = nx1; xb[2] = nx2; xb[3] = nx3;
-  if (u_hist) { u_hist[((size_t)b * steps + step) * 2] = d; u_hist[((size_t)b * steps + step) * 2 + 1] = ac; }
-  if (x_hist) { double* h = x_hist + ((size_t)b * (steps + 1) + step + 1) * 4; h[0] = nx0; h[1] = nx1; h[2] = nx2; h[3] = nx3; }
+  double* xb = x0 + (size_t)b * nx;
+  const double u[2] = {zb[0], zb[1]};
+  double x[MPCB_NX_MAX], f[MPCB_NX_MAX];
+  for (int q = 0; q < nx; ++q) x[q] = xb[q];
+  model_rhs(c, x, u, f);
+  for (int q = 0; q < nx; ++q) xb[q] = x[q] + T * f[q];                          // st = x0 + T f(x0, u[0])
+  if (u_hist) { u_hist[((size_t)b * steps + step) * 2] = u[0]; u_hist[((size_t)b * steps + step) * 2 + 1] = u[1]; }
+  if (x_hist) { double* h = x_hist + ((size_t)b * (steps + 1) + step + 1) * nx; for (int q = 0; q < nx; ++q) h[q] = xb[q]; }
   // u <- [u[1:]; u[-1]],  x_f <- [x_f[1:]; x_f[-1]]
   double* w = z0 + (size_t)b * nz;
   for (int i = 0; i < N; ++i) { int s = (i + 1 < N) ? i + 1 : N - 1; w[2 * i] = zb[2 * s]; w[2 * i + 1] = zb[2 * s + 1]; }
-  for (int i = 0; i <= N; ++i) { int s = (i + 1 <= N) ? i + 1 : N; for (int q = 0; q < 4; ++q) w[2 * N + 4 * i + q] = zb[2 * N + 4 * s + q]; }
+  for (int i = 0; i <= N; ++i) { int s = (i + 1 <= N) ? i + 1 : N; for (int q = 0; q < nx; ++q) w[2 * N + nx * i + q] = zb[2 * N + nx * s + q]; }
   // obstacles move one step with constant velocity and heading (Obs_prediction.py:27-30)
   for (int j = 0; move_obs && j < n_obs; ++j) {
     double* o = obs + ((size_t)b * n_obs + j) * 6;
@@ -522,7 +546,7 @@ int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps, const double* x0,
     if (rc != MPCB_OK) return rc;
     HIP_TRY(h, hipMemcpy2DAsync(d_st + t, (size_t)steps * 4, d_stc, 4, 4, B, hipMemcpyDeviceToDevice, s));
     HIP_TRY(h, hipMemcpy2DAsync(d_it + t, (size_t)steps * 4, d_itc, 4, 4, B, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(mpcb_advance_kin, dim3((B + 127) / 128), dim3(128), 0, s, B, N, nz, no, h->cfg.T, h->cfg.veh_l, d_z, d_x0, d_z0,
+    hipLaunchKernelGGL(mpcb_advance, dim3((B + 127) / 128), dim3(128), 0, s, h->cfg, B, nx, nz, d_z, d_x0, d_z0,
                        d_obs, d_xh, d_uh, t, steps, obs_motion != MPCB_OBSMOVE_STATIC ? 1 : 0);
     HIP_TRY(h, hipGetLastError());
   }
@@ -582,28 +606,9 @@ int mpcb_timing(mpcb_handle* h, int32_t reset, int32_t* launches, double* total_
 
 int mpcb_model_rhs(const mpcb_config* c, const double* x, const double* u, double* xdot) {
   if (!c || !x || !u || !xdot) return MPCB_E_INVALID;
-  if (c->model == MPCB_MODEL_KIN) {                      // kin.py:153-156
-    xdot[0] = x[3] * std::cos(x[2]);
-    xdot[1] = x[3] * std::sin(x[2]);
-    xdot[2] = x[3] * std::tan(u[0]) / c->veh_l;
-    xdot[3] = u[1];
-    return MPCB_OK;
-  }
-  if (c->model == MPCB_MODEL_DYN) {                      // dyn.py:156-170
-    const double phi = x[2], vx = x[3], vy = x[4], r = x[5], df = u[0], ax = u[1];
-    const double af = df - (vy + c->veh_lf * r) / vx, ar = -(vy - c->veh_lr * r) / vx;
-    const double Cf = c->Fymax_f * 2 * c->aopt_f / (c->aopt_f * c->aopt_f + af * af);
-    const double Cr = c->Fymax_r * 2 * c->aopt_r / (c->aopt_r * c->aopt_r + ar * ar);
-    const double Fcf = -Cf * af, Fcr = -Cr * ar;
-    xdot[0] = vx * std::cos(phi) - vy * std::sin(phi);
-    xdot[1] = vx * std::sin(phi) + vy * std::cos(phi);
-    xdot[2] = r;
-    xdot[3] = ax + r * vy;
-    xdot[4] = -r * vx + 2.0 / c->veh_m * (Fcf * std::cos(df) + Fcr);
-    xdot[5] = 2.0 / c->veh_Iz * (c->veh_lf * Fcf - c->veh_lr * Fcr);
-    return MPCB_OK;
-  }
-  return MPCB_E_INVALID;
+  if (c->model != MPCB_MODEL_KIN && c->model != MPCB_MODEL_DYN) return MPCB_E_INVALID;
+  model_rhs(*c, x, u, xdot);
+  return MPCB_OK;
 }
 
 }  // extern "C"
