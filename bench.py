@@ -113,6 +113,9 @@ def main():
                     help="BASELINE.json config: C2 (default, the metric's config) kin+1 static obstacle B=4096; C3 kin+3 predicted "
                          "obstacles B=32768; C4 dyn N=40 3 obstacles B=8192/GPU; C5 closed loop 80 steps (solves = scenes x steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batches", type=int, default=5,
+                    help="distinct synthetic batches resident in HBM, used round-robin by the steps (the launch time of a 4096-instance "
+                         "batch moves +-15 %% with where its slowest instances fall in the dispatch order; one batch would report one draw)")
     ap.add_argument("--warm", action="store_true",
                     help="C2/C3/C4 only: time the NEXT receding-horizon step, started from the shifted solution of a cold solve "
                          "(main_cbf_kin_c_sim.py:16-26,92) instead of the cold start z0=0")
@@ -140,32 +143,42 @@ def main():
     conf = args.config
     B = args.batch or {"C2": 4096, "C3": 32768, "C4": 8192, "C5": 4096}[conf]
     obs_kind = _abi.OBSIN_STATIC
+    NB = 1 if (args.warm or conf == "C5") else max(1, args.batches)
+    sets = []                                               # NB x (x0, xs, obs)
     if conf == "C2":
         cfg = default_config(model=_abi.MODEL_KIN, N=30, T=0.1, n_obs=1)
-        x0, xs, obs = scenes.sample_c2(B, seed=1000 + rank)
+        for q in range(NB):
+            sets.append(scenes.sample_c2(B, seed=q + 16 * rank))          # seeds 0..4
         workload = "C2: kinematic bicycle + 1 static CBF/keep-out obstacle row set (MPC_CBF_optimize_kin), N=30, T=0.1, batch %d random x0 per GPU, cold start z0=0" % B
     elif conf == "C3":
         cfg = default_config(model=_abi.MODEL_KIN, N=30, T=0.1, n_obs=3)
-        x0, xs, _, obs = scenes.sample_c3(B, N=30, dt=0.1, seed=2000 + rank)
+        for q in range(NB):
+            a0, a1, _, a3 = scenes.sample_c3(B, N=30, dt=0.1, seed=100 + q + 16 * rank)
+            sets.append((a0, a1, a3))
         obs_kind = _abi.OBSIN_PREDICTED
         workload = "C3: kinematic bicycle + 3 predicted moving obstacles (MPC_CBF_optimize_kin_pre + Obs_prediction), N=30, batch %d per GPU, cold start" % B
     elif conf == "C4":
         cfg = default_config(model=_abi.MODEL_DYN, N=40, T=0.1, n_obs=3)
-        x0, xs, obs = scenes.sample_c4(B, seed=3000 + rank, n_obs=3)
+        for q in range(NB):
+            sets.append(scenes.sample_c4(B, seed=200 + q + 16 * rank, n_obs=3))
         workload = "C4: dynamic bicycle (MPC_CBF_optimize_dyn, aligned rows), N=40, 3 static obstacles, batch %d per GPU, cold start" % B
     else:
         cfg = default_config(model=_abi.MODEL_KIN, N=30, T=0.1, n_obs=3)
-        x0, xs, obs, _ = scenes.sample_c3(B, N=30, dt=0.1, seed=4000 + rank)
+        a0, a1, a2, _ = scenes.sample_c3(B, N=30, dt=0.1, seed=4000 + rank)
+        sets.append((a0, a1, a2))
         workload = "C5: closed loop, %d scenes per GPU x 80 receding-horizon steps, kinematic bicycle + 3 moving obstacles re-predicted every step" % B
+    x0, xs, obs = sets[0]
     nx, nz, ng = dims(cfg)
     bs = BatchSolver(cfg, device=local_rank)
     if conf == "C5":
         return closed_loop_bench(args, bs, cfg, x0, xs, obs, workload, rank, world)
-    d_x0 = bs.device_array((B, nx)).upload(x0)
-    d_xs = bs.device_array((B, nx)).upload(xs)
-    d_obs = bs.device_array(obs.shape).upload(obs)
+    D = []                                                  # per batch: inputs and the status / iteration outputs, all resident in HBM
+    for (a0, a1, a2) in sets:
+        D.append(dict(x0=bs.device_array((B, nx)).upload(a0), xs=bs.device_array((B, nx)).upload(a1), obs=bs.device_array(a2.shape).upload(a2),
+                      st=bs.device_array((B,), np.int32), it=bs.device_array((B,), np.int32)))
+    d_x0 = D[0]["x0"]
     d_obj = bs.device_array((B,)); d_kkt = bs.device_array((B, 4))
-    d_st = bs.device_array((B,), np.int32); d_it = bs.device_array((B,), np.int32)
+    cyc = [0]                                               # step counter: step k solves batch k mod NB
     if use_dist:    # z lives in torch tensors so that RCCL can gather it; the solver only sees their raw pointers
         z_bufs = [torch.empty((B, nz), dtype=torch.float64, device="cuda") for _ in range(2)]     # double buffer: gather k overlaps solve k+1
         z_all = torch.empty((world * B, nz), dtype=torch.float64, device="cuda")
@@ -189,15 +202,16 @@ def main():
         d_z0 = bs.device_array((B, nz)).upload(z0)
         workload = workload.replace("cold start z0=0", "cold start").replace("cold start", "WARM start: next receding-horizon step from the shifted previous solution")
 
-    def step():
-        if not use_dist:
-            bs.solve_device(B, d_x0, d_xs, d_obs, obs_kind, d_z0, z_ptr, d_obj, d_st, d_it, d_kkt)
+    def step(gather=True):
+        d = D[cyc[0] % NB]; cyc[0] += 1
+        if not (use_dist and gather):
+            bs.solve_device(B, d["x0"], d["xs"], d["obs"], obs_kind, d_z0, z_ptr, d_obj, d["st"], d["it"], d_kkt)
             return
         # N > 1: the gather of step k runs on RCCL's stream while the solve of step k+1 runs on the library's stream
         i = nstep[0] & 1; nstep[0] += 1
         if pending[i] is not None:                      # the gather that last read this buffer (two steps ago) must be done
             pending[i].wait(); torch.cuda.current_stream().synchronize()
-        bs.solve_device(B, d_x0, d_xs, d_obs, obs_kind, d_z0, z_bufs[i].data_ptr(), d_obj, d_st, d_it, d_kkt)
+        bs.solve_device(B, d["x0"], d["xs"], d["obs"], obs_kind, d_z0, z_bufs[i].data_ptr(), d_obj, d["st"], d["it"], d_kkt)
         bs.sync()                                       # host waits for the solve only (it runs on the library's own stream)
         pending[i] = dist.all_gather_into_tensor(z_all, z_bufs[i], async_op=True)
 
@@ -215,6 +229,7 @@ def main():
         step()
     fence()
     bs.timing(reset=True)
+    cyc[0] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -222,13 +237,18 @@ def main():
     dt = time.perf_counter() - t0
     tm = bs.timing()
 
-    status = d_st.download(); iters = d_it.download()
-    solved = int((status == 0).sum())
+    # every batch's status / iteration arrays hold its latest (identical, deterministic) result; weight by how often it ran
+    uses = [args.steps // NB + (1 if q < args.steps % NB else 0) for q in range(NB)]
+    st_b = [d["st"].download() for d in D]; it_b = [d["it"].download() for d in D]
+    solved = sum(u * int((s_ == 0).sum()) for u, s_ in zip(uses, st_b))            # solved instances over all timed steps of this rank
+    status = np.concatenate([s_ for u, s_ in zip(uses, st_b) if u]); iters = np.concatenate([i_ for u, i_ in zip(uses, it_b) if u])
+    iters_per_launch = sum(u * float(i_.sum()) for u, i_ in zip(uses, it_b)) / max(1, args.steps)
     dt_nogather = None
     if use_dist:    # the same K steps once more without the gather, reported next to the headline value
+        cyc[0] = 0
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            bs.solve_device(B, d_x0, d_xs, d_obs, obs_kind, d_z0, z_ptr, d_obj, d_st, d_it, d_kkt)
+            step(gather=False)
         fence()
         dt_nogather = time.perf_counter() - t1
     if use_dist:
@@ -244,16 +264,17 @@ def main():
         abytes = algorithmic_bytes_per_solve(nx, nz, int(obs[0].size)) * B
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
         it_ok = iters[status == 0]
-        flops = (147e3 if cfg.model == _abi.MODEL_DYN else 56e3) * float(iters.sum())   # ~56 kflop (kin N=30) / ~147 kflop (dyn N=40) per iteration
+        flops = (147e3 if cfg.model == _abi.MODEL_DYN else 56e3) * iters_per_launch   # ~56 kflop (kin N=30) / ~147 kflop (dyn N=40) per iteration
         traffic, traffic_src = measured_traffic(workload)
         out = {
-            "metric": "mpc_solves_per_sec", "value": solved_all * args.steps / dt_max, "unit": "solves/s",
+            "metric": "mpc_solves_per_sec", "value": solved_all / dt_max, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "batch_per_gpu": B, "solved_per_step": solved_all, "failed_per_step": world * B - solved_all,
+            "config": {"workload": workload, "batch_per_gpu": B, "distinct_batches": NB,
+                       "solved_per_step": solved_all / args.steps, "failed_per_step": world * B - solved_all / args.steps,
                        "iters_mean_solved": float(it_ok.mean()) if len(it_ok) else None, "iters_max": int(iters.max()),
                        "tol": cfg.tol, "collective": "rccl all_gather of z per step, overlapped with the next step's solve" if use_dist else "none",
-                       "value_without_gather": (solved_all * args.steps / dt_nogather) if dt_nogather else None},
+                       "value_without_gather": (solved_all / dt_nogather) if dt_nogather else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "mpcb_kernel_%s<%d>" % ("dyn" if cfg.model == _abi.MODEL_DYN else "kin", 1 if cfg.n_obs <= 1 else 3), "kernel_ms_avg": kernel_ms,
                          "algorithmic_bytes_per_launch": abytes,
