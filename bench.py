@@ -28,6 +28,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# HIP maps streams onto a small pool of hardware queues (default 4 per process) and two streams on one queue run one
+# after the other; torch + RCCL take several.  More queues keep the solver handles' streams (--inflight) concurrent.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (spec)
 
@@ -113,6 +117,9 @@ def main():
                     help="BASELINE.json config: C2 (default, the metric's config) kin+1 static obstacle B=4096; C3 kin+3 predicted "
                          "obstacles B=32768; C4 dyn N=40 3 obstacles B=8192/GPU; C5 closed loop 80 steps (solves = scenes x steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="solver handles (= HIP streams) used round-robin: step k+1 is launched while the tail of step k drains (a launch "
+                         "ends with its slowest instance and leaves most SIMDs idle before that); 1 = strictly one launch at a time")
     ap.add_argument("--batches", type=int, default=5,
                     help="distinct synthetic batches resident in HBM, used round-robin by the steps (the launch time of a 4096-instance "
                          "batch moves +-15 %% with where its slowest instances fall in the dispatch order; one batch would report one draw)")
@@ -177,15 +184,17 @@ def main():
         D.append(dict(x0=bs.device_array((B, nx)).upload(a0), xs=bs.device_array((B, nx)).upload(a1), obs=bs.device_array(a2.shape).upload(a2),
                       st=bs.device_array((B,), np.int32), it=bs.device_array((B,), np.int32)))
     d_x0 = D[0]["x0"]
-    d_obj = bs.device_array((B,)); d_kkt = bs.device_array((B, 4))
-    cyc = [0]                                               # step counter: step k solves batch k mod NB
+    cyc = [0]                                               # step counter: step k solves batch k mod NB on handle k mod F
+    F = max(1, args.inflight)
+    H = [bs] + [BatchSolver(cfg, device=local_rank) for _ in range(F - 1)]     # one handle = one stream (include/mpcbatch.h)
+    d_obj = [bs.device_array((B,)) for _ in range(F)]; d_kkt = [bs.device_array((B, 4)) for _ in range(F)]
     if use_dist:    # z lives in torch tensors so that RCCL can gather it; the solver only sees their raw pointers
-        z_bufs = [torch.empty((B, nz), dtype=torch.float64, device="cuda") for _ in range(2)]     # double buffer: gather k overlaps solve k+1
+        z_bufs = [torch.empty((B, nz), dtype=torch.float64, device="cuda") for _ in range(max(2, F))]
         z_all = torch.empty((world * B, nz), dtype=torch.float64, device="cuda")
-        z_local = z_bufs[0]; z_ptr = z_local.data_ptr()
-        pending = [None, None]; nstep = [0]
+        z_ptrs = [t.data_ptr() for t in z_bufs]
+        pending = [None] * len(z_bufs); waiting = []        # gathers in flight per z buffer; solves whose gather is not issued yet
     else:
-        d_z = bs.device_array((B, nz)); z_ptr = d_z
+        z_ptrs = [bs.device_array((B, nz)) for _ in range(F)]
 
     d_z0 = None
     if args.warm:
@@ -202,21 +211,32 @@ def main():
         d_z0 = bs.device_array((B, nz)).upload(z0)
         workload = workload.replace("cold start z0=0", "cold start").replace("cold start", "WARM start: next receding-horizon step from the shifted previous solution")
 
+    def issue_gathers(keep):
+        # N > 1: a solve whose successor has been launched is waited for (its handle's stream only) and its z is gathered on
+        # RCCL's stream, while the younger solves keep the GPU busy
+        while len(waiting) > keep:
+            hq, zq = waiting.pop(0)
+            H[hq].sync()
+            pending[zq] = dist.all_gather_into_tensor(z_all, z_bufs[zq], async_op=True)
+
     def step(gather=True):
-        d = D[cyc[0] % NB]; cyc[0] += 1
+        k = cyc[0]; cyc[0] += 1
+        d = D[k % NB]; hq = k % F
         if not (use_dist and gather):
-            bs.solve_device(B, d["x0"], d["xs"], d["obs"], obs_kind, d_z0, z_ptr, d_obj, d["st"], d["it"], d_kkt)
+            H[hq].solve_device(B, d["x0"], d["xs"], d["obs"], obs_kind, d_z0, z_ptrs[hq], d_obj[hq], d["st"], d["it"], d_kkt[hq])
             return
-        # N > 1: the gather of step k runs on RCCL's stream while the solve of step k+1 runs on the library's stream
-        i = nstep[0] & 1; nstep[0] += 1
-        if pending[i] is not None:                      # the gather that last read this buffer (two steps ago) must be done
-            pending[i].wait(); torch.cuda.current_stream().synchronize()
-        bs.solve_device(B, d["x0"], d["xs"], d["obs"], obs_kind, d_z0, z_bufs[i].data_ptr(), d_obj, d["st"], d["it"], d_kkt)
-        bs.sync()                                       # host waits for the solve only (it runs on the library's own stream)
-        pending[i] = dist.all_gather_into_tensor(z_all, z_bufs[i], async_op=True)
+        zq = k % len(z_bufs)
+        if pending[zq] is not None:                     # the gather that last read this buffer must be done
+            pending[zq].wait(); torch.cuda.current_stream().synchronize(); pending[zq] = None
+        H[hq].solve_device(B, d["x0"], d["xs"], d["obs"], obs_kind, d_z0, z_ptrs[zq], d_obj[hq], d["st"], d["it"], d_kkt[hq])
+        waiting.append((hq, zq))
+        issue_gathers(F - 1)
 
     def fence():
-        bs.sync()
+        if use_dist:
+            issue_gathers(0)
+        for h_ in H:
+            h_.sync()
         if use_dist:
             for w in pending:
                 if w is not None:
@@ -228,14 +248,18 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    bs.timing(reset=True)
+    for h_ in H:
+        h_.timing(reset=True)
     cyc[0] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    tm = bs.timing()
+    if use_dist and world == 1:       # one-rank rehearsal of the N > 1 plumbing: the gathered block must equal what the last solve wrote
+        assert torch.equal(z_all[:B], z_bufs[(args.steps - 1) % len(z_bufs)]), "all_gather result differs from the solver output"
+    tms = [h_.timing() for h_ in H]
+    tm = {"total_ms": sum(t_["total_ms"] for t_ in tms), "launches": sum(t_["launches"] for t_ in tms)}
 
     # every batch's status / iteration arrays hold its latest (identical, deterministic) result; weight by how often it ran
     uses = [args.steps // NB + (1 if q < args.steps % NB else 0) for q in range(NB)]
@@ -273,24 +297,24 @@ def main():
             "config": {"workload": workload, "batch_per_gpu": B, "distinct_batches": NB,
                        "solved_per_step": solved_all / args.steps, "failed_per_step": world * B - solved_all / args.steps,
                        "iters_mean_solved": float(it_ok.mean()) if len(it_ok) else None, "iters_max": int(iters.max()),
-                       "tol": cfg.tol, "collective": "rccl all_gather of z per step, overlapped with the next step's solve" if use_dist else "none",
+                       "launches_in_flight": F, "tol": cfg.tol, "collective": "rccl all_gather of z per step, overlapped with the next step's solve" if use_dist else "none",
                        "value_without_gather": (solved_all / dt_nogather) if dt_nogather else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "mpcb_kernel_%s<%d>" % ("dyn" if cfg.model == _abi.MODEL_DYN else "kin", 1 if cfg.n_obs <= 1 else 3), "kernel_ms_avg": kernel_ms,
                          "algorithmic_bytes_per_launch": abytes,
+                         "achieved_over_wall_clock": abytes * args.steps / dt_max / 1e9,   # launches overlap (launches_in_flight): each one lasts longer than a step
+
                          "note": "compulsory I/O is 3072 B/solve; the solve is LDS-resident, bound by FP64 VALU issue and the serial "
                                  "Riccati chain, not by HBM (SURVEY.md F10, DESIGN.md §5)"},
-            "roofline_fp64": {"bound": "fp64_valu", "achieved": flops / (kernel_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": flops / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                              "model": "56 kflop x interior-point iterations summed over the batch"},
+            "roofline_fp64": {"bound": "fp64_valu", "achieved": flops * args.steps / dt_max / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": flops * args.steps / dt_max / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                              "model": "56 kflop x interior-point iterations summed over the batch, per step, over the wall clock of the "
+                                       "timed region (launches overlap, so a launch lasts longer than a step)"},
         }
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, x0, xs, obs)
         print(json.dumps(out))
     if use_dist:
-        z_local = z_bufs[(nstep[0] - 1) & 1]
-        if rank == 0 and world == 1:      # rehearsal: the gathered block must equal what the solver wrote
-            assert torch.equal(z_all[:B], z_local), "all_gather result differs from the solver output"
         dist.barrier()
         dist.destroy_process_group()
 
