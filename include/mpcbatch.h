@@ -21,7 +21,9 @@
  *     z[2N + nx*k + s] = X[s,k]                                  CMOM/MPC_CBF_optimize_kin.py:160-161,250
  *   - constraint row order (g, lbg, ubg) is the reference's       CMOM/MPC_CBF_optimize_kin.py:107-132,190-247
  *   - per-instance solver outcome goes to status[] (MPCB_ST_*), never to the return code.
- *   - one handle = one device + one stream; calls on one handle must be serialised by the caller.
+ *   - one handle = one device + one stream; calls on one handle must be serialised by the caller.  Distinct handles are
+ *     independent: their launches overlap on the GPU, which is how throughput is kept up while the slowest instances of
+ *     a launch finish (bench.py keeps three handles in flight).
  */
 #ifndef MPCBATCH_H
 #define MPCBATCH_H
