@@ -411,3 +411,25 @@ def test_closed_loop_on_device_dynamic_model(gpu_solver_factory):
     assert good.sum() >= 6 and dev["x_hist"].shape == (B, steps + 1, 6)
     assert np.abs(np.stack(xh, axis=1)[good] - dev["x_hist"][good]).max() <= 1e-6
     assert np.abs(dev["u_hist"][good, 0] - bs.solve_batch(x0, xs, obs)["z"][good, :2]).max() <= 1e-9
+
+
+def test_two_handles_in_flight_give_the_same_results(gpu_solver_factory):
+    """Launches of distinct handles overlap on the GPU (bench.py keeps three in flight): the results must be those of the
+    same solves run one after the other."""
+    cfg = default_config(N=30, n_obs=1)
+    a, b = gpu_solver_factory(cfg), gpu_solver_factory(cfg)
+    B = 2048
+    xa, xs, oa = scenes.sample_c2(B, seed=71); xb, _, ob = scenes.sample_c2(B, seed=72)
+    ra = a.solve_batch(xa, xs, oa); rb = b.solve_batch(xb, xs, ob)                        # one after the other
+    d = {}
+    for name, h, x0, ob_ in (("a", a, xa, oa), ("b", b, xb, ob)):
+        d[name] = dict(x0=h.device_array((B, 4)).upload(x0), xs=h.device_array((B, 4)).upload(xs), obs=h.device_array(ob_.shape).upload(ob_),
+                       z=h.device_array((B, 184)), st=h.device_array((B,), np.int32), it=h.device_array((B,), np.int32))
+    for _ in range(3):                                                                     # both in flight, three rounds
+        for name, h in (("a", a), ("b", b)):
+            q = d[name]
+            h.solve_device(B, q["x0"], q["xs"], q["obs"], _abi.OBSIN_STATIC, None, q["z"], None, q["st"], q["it"], None)
+    a.sync(); b.sync()
+    for name, r in (("a", ra), ("b", rb)):
+        assert np.array_equal(d[name]["st"].download(), r["status"]) and np.array_equal(d[name]["it"].download(), r["iters"])
+        assert np.array_equal(d[name]["z"].download(), r["z"])                            # bit for bit: the kernel is deterministic
