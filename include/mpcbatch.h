@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MPCB_ABI_VERSION 1
+#define MPCB_ABI_VERSION 2
 
 /* return codes */
 #define MPCB_OK              0
@@ -46,9 +46,14 @@ extern "C" {
 /* per-instance status */
 #define MPCB_ST_SOLVED        0  /* scaled NLP error <= tol (IPOPT "Optimal Solution Found") */
 #define MPCB_ST_MAXITER       1  /* max_iter reached; last iterate returned (the reference ignores status too) */
-#define MPCB_ST_LINESEARCH    2  /* no acceptable step (where IPOPT would enter restoration) */
+#define MPCB_ST_LINESEARCH    2  /* no acceptable step and cfg.restoration == 0 (where IPOPT would enter restoration) */
 #define MPCB_ST_INFEASIBLE_X0 3  /* x0 violates a state box or lies inside an obstacle row at node 0 */
 #define MPCB_ST_NUMERIC       4  /* regularisation exhausted or non-finite number */
+#define MPCB_ST_INFEASIBLE    5  /* the restoration phase converged to a stationary point of the constraint violation with
+                                    violation > tol: LOCAL infeasibility (IPOPT "Converged to a point of local infeasibility.
+                                    Problem may be infeasible", return_status Infeasible_Problem_Detected) */
+#define MPCB_ST_RESTO_FAILED  6  /* the restoration phase itself found no acceptable step / ran into max_iter without reducing
+                                    the violation (IPOPT "Restoration_Failed") */
 
 /* models                                                     reference */
 #define MPCB_MODEL_KIN 0      /* 4-state kinematic bicycle     CMOM/MPC_CBF_optimize_kin.py:153-156 */
@@ -58,9 +63,12 @@ extern "C" {
 #define MPCB_OBS_KEEPOUT 0    /* h_j(X_i) >= 0, the shipped form          CMOM/MPC_CBF_optimize_kin.py:247 */
 #define MPCB_OBS_DCBF    1    /* gamma*h_i(X_i) + h_i(X_{i+1}) - h_i(X_i) >= 0, the commented form   kin.py:245-248 */
 
-/* barrier-parameter strategies */
-#define MPCB_MU_MONOTONE 0    /* IPOPT default: Fiacco-McCormick, mu_init = 0.1, kappa_mu = 0.2, theta_mu = 1.5 */
-#define MPCB_MU_ADAPTIVE 1    /* Mehrotra probing: sigma = (mu_aff/mu)^3 + second-order corrector (IPOPT mu_oracle = probing) */
+/* barrier-parameter strategy: IPOPT's default (monotone Fiacco-McCormick, kappa_mu = 0.2, theta_mu = 1.5) is the only one */
+#define MPCB_MU_MONOTONE 0
+
+/* integrator of the shooting rows */
+#define MPCB_INT_EULER 0      /* X_{i+1} = X_i + T f(X_i,U_i): what the reference's NLP and plant use   kin.py:207, main_cbf_kin_c_sim.py:17-18 */
+#define MPCB_INT_RK4   1      /* named by BASELINE.json's north_star; not in the reference -> mpcb_create returns MPCB_E_UNSUPPORTED */
 
 /* obstacle input kinds for mpcb_solve */
 #define MPCB_OBSIN_STATIC    0 /* [B, n_obs, 6]       rows [x,y,theta,v,l,w]   CMOM/main_cbf_kin_c_sim.py:55 */
@@ -82,9 +90,12 @@ typedef struct mpcb_config {
   int32_t  rate_interleaved;  /* order of the rate rows inside g: 0 = one block after all dynamics rows (kin.py:211-216),
                                  1 = after each stage's dynamics rows (dyn.py:226-231).  Affects lam_g / bounds order only. */
   int32_t  max_iter;          /* ipopt.max_iter = 100                     kin.py:252 */
-  int32_t  mu_strategy;       /* MPCB_MU_* : barrier update rule */
+  int32_t  mu_strategy;       /* MPCB_MU_MONOTONE */
   int32_t  init_rollout;      /* 0: take the X part of the start as given (what IPOPT receives);
                                  1: keep U of the start, roll X out from x0 with the model (multiple-shooting warm start) */
+  int32_t  integrator;        /* MPCB_INT_EULER (the reference); MPCB_INT_RK4 is rejected */
+  int32_t  restoration;       /* 1 (default): a failed line search enters the feasibility-restoration phase (IPOPT's default
+                                 behaviour); 0: it ends the solve with MPCB_ST_LINESEARCH (abi 1 behaviour) */
   double   T;                 /* T_S */
   double   gamma;             /* DCBF gamma in (0, 1] (kin.py:235 sets 1.0); < 1: kinematic model only, rows i = 0..N-1 */
   double   Q[MPCB_NX_MAX];    /* diag of Q                                kin.py:168-172 */
@@ -103,7 +114,7 @@ typedef struct mpcb_config {
   double   Fymax_f, Fymax_r, aopt_f, aopt_r;   /* dyn tyre                dyn.py:158-159 */
   /* interior-point options: IPOPT's documented defaults unless the reference sets them (kin.py:252-253) */
   double   tol;               /* 1e-8 */
-  double   mu_init;           /* 0.1 */
+  double   mu_init;           /* IPOPT: 0.1; mpcb_default_config sets 10 because its start (init_rollout = 1) is dynamics-feasible */
   double   bound_push;        /* 0.01 (kappa_1) */
   double   bound_frac;        /* 0.01 (kappa_2) */
   double   bound_relax;       /* 1e-8 (bound_relax_factor) */
@@ -166,15 +177,23 @@ int mpcb_solve_device(mpcb_handle* h, int32_t B,
  *   obs_state [B, n_obs, 6] in/out
  *   obs_motion  MPCB_OBSMOVE_STATIC    obstacles never move, rows use obs_state as is      (main_cbf_kin_c_sim.py:55,99)
  *               MPCB_OBSMOVE_PREDICTED constant-velocity obstacles (Obs_prediction.py:27-30): predicted over the horizon
- *                                      for every solve, advanced one step per MPC step       (main_cbf_kin_c_sim_pre.py:98-106;
- *                                      the reference advances only its first obstacle, here all of them)
+ *                                      for every solve, advanced one step per MPC step       (main_cbf_kin_c_sim_pre.py:98-106)
  *               MPCB_OBSMOVE_CURRENT   advanced one step per MPC step, rows use the current position at every node
  *   x_hist [B, steps+1, nx], u_hist [B, steps, 2] (may be NULL), status_hist [B, steps], iters_hist [B, steps] */
 #define MPCB_OBSMOVE_STATIC    0
 #define MPCB_OBSMOVE_PREDICTED 1
 #define MPCB_OBSMOVE_CURRENT   2
+/* flags (or-ed):
+ *   MPCB_CL_HOLD_ON_FAILURE   an instance whose solve does not end with MPCB_ST_SOLVED applies the first control of its PREVIOUS
+ *                             plan and keeps that plan, shifted, as the next warm start (hold-and-shift; prior art in the
+ *                             reference tree: `reference code/MPC-D-CBF.py:341-353`).  Without it the failed iterate is applied,
+ *                             which is what the reference's drivers do (they never read IPOPT's status, main_cbf_kin_c_sim.py:100-104).
+ *   MPCB_CL_ADVANCE_FIRST_ONLY only obstacle 0 moves between MPC steps: main_cbf_kin_c_sim_pre.py:106 rebuilds its obstacle list
+ *                             from the first predicted trajectory alone; without the flag every obstacle moves. */
+#define MPCB_CL_HOLD_ON_FAILURE    1
+#define MPCB_CL_ADVANCE_FIRST_ONLY 2
 int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps,
-                     const double* x0, const double* xs, double* obs_state, int32_t obs_motion,
+                     const double* x0, const double* xs, double* obs_state, int32_t obs_motion, int32_t flags,
                      double* x_hist, double* u_hist, int32_t* status_hist, int32_t* iters_hist);
 
 /* device memory helpers so that Python (ctypes, no torch) can keep batches resident */

@@ -5,15 +5,18 @@ tests/test_abi.py checks sizeof and the exported symbols against the header.
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, E_INVALID, E_BOUNDS, E_DEVICE, E_UNSUPPORTED = 0, -1, -2, -3, -4
-ST_SOLVED, ST_MAXITER, ST_LINESEARCH, ST_INFEASIBLE_X0, ST_NUMERIC = 0, 1, 2, 3, 4
-STATUS_NAMES = {0: "solved", 1: "max_iter", 2: "line_search", 3: "infeasible_x0", 4: "numeric"}
+ST_SOLVED, ST_MAXITER, ST_LINESEARCH, ST_INFEASIBLE_X0, ST_NUMERIC, ST_INFEASIBLE, ST_RESTO_FAILED = 0, 1, 2, 3, 4, 5, 6
+STATUS_NAMES = {0: "solved", 1: "max_iter", 2: "line_search", 3: "infeasible_x0", 4: "numeric", 5: "locally_infeasible",
+                6: "restoration_failed"}
 MODEL_KIN, MODEL_DYN = 0, 1
 OBS_KEEPOUT, OBS_DCBF = 0, 1
 OBSIN_STATIC, OBSIN_PREDICTED = 0, 1
-MU_MONOTONE, MU_ADAPTIVE = 0, 1
+MU_MONOTONE = 0
+INT_EULER, INT_RK4 = 0, 1
+CL_HOLD_ON_FAILURE, CL_ADVANCE_FIRST_ONLY = 1, 2
 OBSMOVE_STATIC, OBSMOVE_PREDICTED, OBSMOVE_CURRENT = 0, 1, 2
 NX_MAX, NU, NOBS_MAX, N_MAX = 6, 2, 8, 63
 
@@ -26,6 +29,7 @@ class MpcbConfig(C.Structure):
         ("struct_size", C.c_uint32),
         ("model", _i), ("N", _i), ("n_obs", _i), ("obs_mode", _i), ("obs_terminal", _i),
         ("du0_cost", _i), ("rate_interleaved", _i), ("max_iter", _i), ("mu_strategy", _i), ("init_rollout", _i),
+        ("integrator", _i), ("restoration", _i),
         ("T", _d), ("gamma", _d),
         ("Q", _d * NX_MAX), ("R", _d * NU), ("DR", _d * NU), ("u_last", _d * NU),
         ("u_lo", _d * NU), ("u_hi", _d * NU),

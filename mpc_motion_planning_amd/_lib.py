@@ -28,7 +28,7 @@ SIGNATURES = {
     "mpcb_solve_device": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "mpcb_solve_trace": (C.c_int, [_H, _PD, _PD, _PD, C.c_int32, _PD, _PD, _PI, _PI, _PD]),
-    "mpcb_closed_loop": (C.c_int, [_H, C.c_int32, C.c_int32, _PD, _PD, _PD, C.c_int32, _PD, _PD, _PI, _PI]),
+    "mpcb_closed_loop": (C.c_int, [_H, C.c_int32, C.c_int32, _PD, _PD, _PD, C.c_int32, C.c_int32, _PD, _PD, _PI, _PI]),
     "mpcb_dev_alloc": (C.c_int, [_H, C.c_uint64, C.POINTER(C.c_void_p)]),
     "mpcb_dev_free": (C.c_int, [_H, C.c_void_p]),
     "mpcb_dev_upload": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_uint64]),

@@ -16,9 +16,11 @@ from .solver import BatchSolver, default_config, model_rhs
 _RETURN_STATUS = {
     _abi.ST_SOLVED: "Solve_Succeeded",
     _abi.ST_MAXITER: "Maximum_Iterations_Exceeded",
-    _abi.ST_LINESEARCH: "Restoration_Failed",
-    _abi.ST_INFEASIBLE_X0: "Infeasible_Problem_Detected",
+    _abi.ST_LINESEARCH: "Line_Search_Failed_Restoration_Disabled",   # cfg.restoration = 0: no restoration was attempted
+    _abi.ST_INFEASIBLE_X0: "Infeasible_Problem_Detected",              # x0 violates a row of node 0: no z can satisfy it
     _abi.ST_NUMERIC: "Error_In_Step_Computation",
+    _abi.ST_INFEASIBLE: "Infeasible_Problem_Detected",                 # restoration converged to a point of LOCAL infeasibility
+    _abi.ST_RESTO_FAILED: "Restoration_Failed",
 }
 
 
@@ -176,6 +178,26 @@ class MpcBase:
             bs = BatchSolver(cfg)
             self._solvers[key] = bs
         return bs
+
+    def generate_ref_path(self, x0, xs):
+        """Quintic lane-change reference (kin.py:258-308; never called by the reference's drivers, kept for the surface):
+        over the first 3 s a fifth-order polynomial in x and in y from (x0, vx0, 0 acceleration) to (x0 + vxs*3, y_s, vx_s), then a
+        straight extension at the set-point speed up to T_horizon; sampled every 0.1 s.  Returns rows [x, y, heading in DEGREES, v]."""
+        x0 = np.asarray(x0, dtype=np.float64).reshape(-1); xs = np.asarray(xs, dtype=np.float64).reshape(-1)
+        t_blend, dt = 3.0, 0.1
+        n1, n2 = int(t_blend / dt), int((self.T_horizon - t_blend) / dt)
+        ta = np.linspace(0.0, t_blend, n1); tb = np.linspace(t_blend, self.T_horizon, n2 + 1)
+        pw = lambda t, d: np.array([0.0 if k < d else np.prod(np.arange(k, k - d, -1.0)) * t ** (k - d) for k in range(6)])  # noqa: E731
+        A = np.array([pw(0.0, 0), pw(0.0, 1), pw(0.0, 2), pw(t_blend, 0), pw(t_blend, 1), pw(t_blend, 2)])
+        cx = np.linalg.solve(A, np.array([x0[0], x0[3], 0.0, xs[3] * t_blend + x0[0], xs[3], 0.0]))
+        cy = np.linalg.solve(A, np.array([x0[1], 0.0, 0.0, xs[1], 0.0, 0.0]))
+        P = np.stack([ta ** k for k in range(6)], axis=1)
+        dP = np.stack([np.zeros_like(ta)] + [k * ta ** (k - 1) for k in range(1, 6)], axis=1)
+        xa, ya = P @ cx, P @ cy
+        heading = np.degrees(np.arctan2(dP @ cy, dP @ cx))
+        xb = xa[-1] + xs[3] * (tb - ta[-1])
+        return np.column_stack((np.concatenate((xa, xb)), np.concatenate((ya, np.full_like(tb, ya[-1]))),
+                                np.concatenate((heading, np.full_like(tb, heading[-1]))), np.full(n1 + n2 + 1, xs[3])))
 
     # ----- bounds in the reference's z / g order ---------------------------------------------------------------
     def _box_lists(self):

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(64, MPCB_WAVES_PER_SIMD) void mpcb_kernel_dyn(const
 
 // f(x,u) of the configured model: the reference's `mpc_solver.f` (kin.py:153-159, dyn.py:156-177); host and device
 __host__ __device__ inline void model_rhs(const mpcb_config& c, const double* x, const double* u, double* xdot) {
+#pragma clang fp contract(off)   // every product and sum rounded on its own, as numpy / CasADi evaluate the reference's expressions
   if (c.model == MPCB_MODEL_KIN) {                       // kin.py:153-156
     xdot[0] = x[3] * cos(x[2]);
     xdot[1] = x[3] * sin(x[2]);
@@ -60,28 +61,52 @@ __host__ __device__ inline void model_rhs(const mpcb_config& c, const double* x,
 // closed-loop helper: plant step with the first control, warm-start shift, obstacle advance; either model.
 // one thread per instance (tiny, HBM-bound, runs between two solves of the closed loop)
 //   main_cbf_kin_c_sim.py:16-26 / main_cbf_dyn_c_sim.py:15-25 (shift_movement), main_cbf_kin_c_sim_pre.py:106 (obstacle advance)
-__global__ void mpcb_advance(const mpcb_config c, int B, int nx, int nz, const double* __restrict__ z,
-                             double* __restrict__ x0, double* __restrict__ z0, double* __restrict__ obs,
-                             double* __restrict__ x_hist, double* __restrict__ u_hist, int step, int steps, int move_obs) {
+// NX is a template parameter so that x[] / f[] live in registers (with a run-time nx the compiler parked them in LDS).
+//   move_obs: 0 none, 1 every obstacle one constant-velocity step, 2 only the first one (what main_cbf_kin_c_sim_pre.py:106 does)
+//   hold: 1 = an instance whose solve did not end with MPCB_ST_SOLVED applies its previous plan instead (the shifted warm start
+//         z0 IS that plan, already moved one step): hold-and-shift, prior art `reference code/MPC-D-CBF.py:341-353`
+template <int NX>
+__global__ __launch_bounds__(128) void mpcb_advance(const mpcb_config c, int B, int nz, const double* __restrict__ z,
+                                                    double* __restrict__ x0, double* __restrict__ z0, double* __restrict__ obs,
+                                                    double* __restrict__ x_hist, double* __restrict__ u_hist,
+                                                    const int32_t* __restrict__ status, int st_stride, int step, int steps,
+                                                    int move_obs, int hold) {
+#pragma clang fp contract(off)   // st = x0 + T*f and x += v*cos(theta)*dt with numpy's roundings (no FMA): bit-equal to the reference's helpers
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int N = c.N, n_obs = c.n_obs;
   const double T = c.T;
-  const double* zb = z + (size_t)b * nz;
-  double* xb = x0 + (size_t)b * nx;
-  const double u[2] = {zb[0], zb[1]};
-  double x[MPCB_NX_MAX], f[MPCB_NX_MAX];
-  for (int q = 0; q < nx; ++q) x[q] = xb[q];
-  model_rhs(c, x, u, f);
-  for (int q = 0; q < nx; ++q) xb[q] = x[q] + T * f[q];                          // st = x0 + T f(x0, u[0])
-  if (u_hist) { u_hist[((size_t)b * steps + step) * 2] = u[0]; u_hist[((size_t)b * steps + step) * 2 + 1] = u[1]; }
-  if (x_hist) { double* h = x_hist + ((size_t)b * (steps + 1) + step + 1) * nx; for (int q = 0; q < nx; ++q) h[q] = xb[q]; }
-  // u <- [u[1:]; u[-1]],  x_f <- [x_f[1:]; x_f[-1]]
   double* w = z0 + (size_t)b * nz;
-  for (int i = 0; i < N; ++i) { int s = (i + 1 < N) ? i + 1 : N - 1; w[2 * i] = zb[2 * s]; w[2 * i + 1] = zb[2 * s + 1]; }
-  for (int i = 0; i <= N; ++i) { int s = (i + 1 <= N) ? i + 1 : N; for (int q = 0; q < nx; ++q) w[2 * N + nx * i + q] = zb[2 * N + nx * s + q]; }
+  // the plan that is executed: this step's solution, or (hold) the previous plan kept in z0
+  const bool keep = hold && status && status[(size_t)b * st_stride] != MPCB_ST_SOLVED;
+  const double* zb = keep ? w : z + (size_t)b * nz;
+  double* xb = x0 + (size_t)b * NX;
+  const double u[2] = {zb[0], zb[1]};
+  double x[MPCB_NX_MAX] = {0, 0, 0, 0, 0, 0}, f[MPCB_NX_MAX];   // constant indices after unrolling: registers
+#pragma unroll
+  for (int q = 0; q < NX; ++q) x[q] = xb[q];
+  model_rhs(c, x, u, f);
+#pragma unroll
+  for (int q = 0; q < NX; ++q) xb[q] = x[q] + T * f[q];                          // st = x0 + T f(x0, u[0])
+  if (u_hist) { u_hist[((size_t)b * steps + step) * 2] = u[0]; u_hist[((size_t)b * steps + step) * 2 + 1] = u[1]; }
+  if (x_hist) {
+    double* h = x_hist + ((size_t)b * (steps + 1) + step + 1) * NX;
+#pragma unroll
+    for (int q = 0; q < NX; ++q) h[q] = xb[q];
+  }
+  // u <- [u[1:]; u[-1]],  x_f <- [x_f[1:]; x_f[-1]]   (in place when zb == w: ascending order reads ahead of the writes)
+  for (int i = 0; i < N; ++i) { int s = (i + 1 < N) ? i + 1 : N - 1; const double a0 = zb[2 * s], a1 = zb[2 * s + 1]; w[2 * i] = a0; w[2 * i + 1] = a1; }
+  for (int i = 0; i <= N; ++i) {
+    int s = (i + 1 <= N) ? i + 1 : N;
+    double t[NX];
+#pragma unroll
+    for (int q = 0; q < NX; ++q) t[q] = zb[2 * N + NX * s + q];
+#pragma unroll
+    for (int q = 0; q < NX; ++q) w[2 * N + NX * i + q] = t[q];
+  }
   // obstacles move one step with constant velocity and heading (Obs_prediction.py:27-30)
-  for (int j = 0; move_obs && j < n_obs; ++j) {
+  const int nmove = move_obs == 1 ? n_obs : move_obs == 2 ? (n_obs < 1 ? n_obs : 1) : 0;
+  for (int j = 0; j < nmove; ++j) {
     double* o = obs + ((size_t)b * n_obs + j) * 6;
     o[0] += o[3] * cos(o[2]) * T; o[1] += o[3] * sin(o[2]) * T;
   }
@@ -89,6 +114,7 @@ __global__ void mpcb_advance(const mpcb_config c, int B, int nx, int nz, const d
 
 // constant-velocity prediction of every obstacle over the horizon: [B, n_obs, 6] -> [B, n_obs, N+1, 6]
 __global__ void mpcb_predict_obs(int total, int N, double T, const double* __restrict__ obs, double* __restrict__ traj) {
+#pragma clang fp contract(off)   // next_x = x + v*cos(theta)*dt, two roundings per step as in Obs_prediction.py:27-28
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const double* o = obs + (size_t)i * 6;
@@ -109,11 +135,14 @@ struct mpcb_handle {
   hipStream_t stream = nullptr;
   std::string err;
   int nx = 4, nz = 0, ng = 0;
-  // scratch for the host-pointer entry
+  // scratch for the host-pointer entries
   void* d_buf = nullptr; size_t d_cap = 0;
-  // timing
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  // timing: a ring of event pairs created once; a pair is harvested (synchronised, accumulated) before it is reused
+  static constexpr int EV_RING = 256;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;   // EV_RING pairs, created on first use
+  int ev_head = 0, ev_pending = 0;                     // next pair to record into; pairs recorded and not yet harvested
   int launches = 0; double total_ms = 0, last_ms = 0;
+  bool lds_attr_set = false;                           // hipFuncAttributeMaxDynamicSharedMemorySize applied to this handle's kernel
 };
 
 namespace {
@@ -149,7 +178,13 @@ int check_cfg(mpcb_handle* h, const mpcb_config* c) {
   if (c->obs_mode == MPCB_OBS_DCBF && c->gamma < 1.0 - 1e-12 && (c->model != MPCB_MODEL_KIN || c->obs_terminal))
     return fail(h, MPCB_E_UNSUPPORTED, "general-gamma discrete-CBF rows are implemented for the kinematic model with rows i = 0..N-1");
   if (c->obs_mode != MPCB_OBS_KEEPOUT && c->obs_mode != MPCB_OBS_DCBF) return fail(h, MPCB_E_INVALID, "unknown obs_mode %d", c->obs_mode);
-  if (c->mu_strategy != MPCB_MU_MONOTONE) return fail(h, MPCB_E_UNSUPPORTED, "only MPCB_MU_MONOTONE is implemented on the device");
+  if (c->obs_mode == MPCB_OBS_DCBF && c->obs_terminal)
+    return fail(h, MPCB_E_UNSUPPORTED, "discrete-CBF rows exist for i = 0..N-1 only (row N would need X_{N+1}, kin.py:236-248): obs_terminal must be 0");
+  if (c->mu_strategy != MPCB_MU_MONOTONE) return fail(h, MPCB_E_INVALID, "unknown mu_strategy %d (MPCB_MU_MONOTONE is the only one)", c->mu_strategy);
+  if (c->integrator == MPCB_INT_RK4)
+    return fail(h, MPCB_E_UNSUPPORTED, "MPCB_INT_RK4: the reference's NLP and plant are explicit Euler (kin.py:207); no RK4 mode is built");
+  if (c->integrator != MPCB_INT_EULER) return fail(h, MPCB_E_INVALID, "unknown integrator %d", c->integrator);
+  if (c->restoration != 0 && c->restoration != 1) return fail(h, MPCB_E_INVALID, "restoration must be 0 or 1");
   if (std::isfinite(c->x_lo[0]) || std::isfinite(c->x_hi[0]) || std::isfinite(c->x_lo[2]) || std::isfinite(c->x_hi[2]))
     return fail(h, MPCB_E_UNSUPPORTED, "state boxes are supported on y, vx (and vy for the dynamic model) (kin.py:97-105, dyn.py:97-110)");
   if (c->model == MPCB_MODEL_KIN) {
@@ -169,73 +204,62 @@ size_t lds_bytes(const mpcb_config& c, int nz) {
   return (size_t)(c.model == MPCB_MODEL_DYN ? mpcbk::layout_dyn(c.N).total : mpcbk::layout_kin(c.N, nz).total) * sizeof(double);
 }
 
-int launch_solve(mpcb_handle* h, const MpcbKArgs& a) {
-  const size_t lds = lds_bytes(h->cfg, h->nz);
-  if (lds > 160 * 1024) return fail(h, MPCB_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds);
-  if (a.B == 0) return MPCB_OK;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  HIP_TRY(h, hipEventCreate(&e0));
-  HIP_TRY(h, hipEventCreate(&e1));
-  HIP_TRY(h, hipEventRecord(e0, h->stream));
-  const dim3 grid(a.B), block(64);
-  const int n = h->cfg.n_obs;
-#define LAUNCH(NOBS)                                                                                           \
-  do {                                                                                                         \
-    if (lds > 48 * 1024)                                                                                       \
-      HIP_TRY(h, hipFuncSetAttribute((const void*)mpcb_kernel_kin<NOBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(mpcb_kernel_kin<NOBS>, grid, block, lds, h->stream, a);                                 \
-  } while (0)
-#define LAUNCH_DYN(NOBS)                                                                                       \
-  do {                                                                                                         \
-    if (lds > 48 * 1024)                                                                                       \
-      HIP_TRY(h, hipFuncSetAttribute((const void*)mpcb_kernel_dyn<NOBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(mpcb_kernel_dyn<NOBS>, grid, block, lds, h->stream, a);                                 \
-  } while (0)
-  if (h->cfg.model == MPCB_MODEL_DYN) {
-    if (n <= 1) LAUNCH_DYN(1);
-    else if (n <= 3) LAUNCH_DYN(3);
-    else if (n <= 5) LAUNCH_DYN(5);
-    else LAUNCH_DYN(8);
-  } else if (h->cfg.obs_mode == MPCB_OBS_DCBF && h->cfg.gamma < 1.0 - 1e-12 && n > 0) {   // general-gamma CBF rows
-#define LAUNCH_GEN(NOBS)                                                                                       \
-  do {                                                                                                         \
-    if (lds > 48 * 1024)                                                                                       \
-      HIP_TRY(h, hipFuncSetAttribute((const void*)mpcb_kernel_kin<NOBS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((mpcb_kernel_kin<NOBS, true>), grid, block, lds, h->stream, a);                         \
-  } while (0)
-    if (n == 1) LAUNCH_GEN(1);
-    else if (n <= 3) LAUNCH_GEN(3);
-    else LAUNCH_GEN(8);
-#undef LAUNCH_GEN
-  } else if (n == 0) LAUNCH(0);
-  else if (n == 1) LAUNCH(1);
-  else if (n <= 3) LAUNCH(3);
-  else if (n <= 5) LAUNCH(5);
-  else LAUNCH(8);
-#undef LAUNCH
-#undef LAUNCH_DYN
-  HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipEventRecord(e1, h->stream));
-  h->ev.emplace_back(e0, e1);
-  if (h->ev.size() > 8192) {   // bound the number of live events
-    HIP_TRY(h, hipEventSynchronize(h->ev.front().second));
-    float ms = 0; (void)hipEventElapsedTime(&ms, h->ev.front().first, h->ev.front().second);
-    h->total_ms += ms; h->last_ms = ms; ++h->launches;
-    (void)hipEventDestroy(h->ev.front().first); (void)hipEventDestroy(h->ev.front().second);
-    h->ev.erase(h->ev.begin());
-  }
+// oldest recorded pair -> total_ms / last_ms / launches
+int harvest_one(mpcb_handle* h) {
+  const int i = (h->ev_head - h->ev_pending + 2 * mpcb_handle::EV_RING) % mpcb_handle::EV_RING;
+  HIP_TRY(h, hipEventSynchronize(h->ev[i].second));
+  float ms = 0;
+  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev[i].first, h->ev[i].second));
+  h->total_ms += ms; h->last_ms = ms; ++h->launches; --h->ev_pending;
   return MPCB_OK;
 }
 
 int collect_timing(mpcb_handle* h) {
-  for (auto& p : h->ev) {
-    HIP_TRY(h, hipEventSynchronize(p.second));
-    float ms = 0;
-    HIP_TRY(h, hipEventElapsedTime(&ms, p.first, p.second));
-    h->total_ms += ms; h->last_ms = ms; ++h->launches;
-    (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+  while (h->ev_pending > 0) { int rc = harvest_one(h); if (rc != MPCB_OK) return rc; }
+  return MPCB_OK;
+}
+
+template <class K>
+int launch_kernel(mpcb_handle* h, K kernel, const MpcbKArgs& a, size_t lds) {
+  if (lds > 48 * 1024 && !h->lds_attr_set) {   // once per handle: one handle = one device + one kernel instantiation
+    HIP_TRY(h, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->lds_attr_set = true;
   }
-  h->ev.clear();
+  hipLaunchKernelGGL(kernel, dim3(a.B), dim3(64), lds, h->stream, a);
+  return MPCB_OK;
+}
+
+int launch_solve(mpcb_handle* h, const MpcbKArgs& a) {
+  const size_t lds = lds_bytes(h->cfg, h->nz);
+  if (lds > 160 * 1024) return fail(h, MPCB_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds);
+  if (a.B == 0) return MPCB_OK;
+  if (h->ev.empty()) {
+    h->ev.resize(mpcb_handle::EV_RING);
+    for (auto& p : h->ev) { HIP_TRY(h, hipEventCreate(&p.first)); HIP_TRY(h, hipEventCreate(&p.second)); }
+  }
+  if (h->ev_pending == mpcb_handle::EV_RING) { int rc = harvest_one(h); if (rc != MPCB_OK) return rc; }
+  auto& evp = h->ev[h->ev_head];
+  HIP_TRY(h, hipEventRecord(evp.first, h->stream));
+  const int n = h->cfg.n_obs;
+  int rc = MPCB_OK;
+  if (h->cfg.model == MPCB_MODEL_DYN) {
+    if (n <= 1) rc = launch_kernel(h, mpcb_kernel_dyn<1>, a, lds);
+    else if (n <= 3) rc = launch_kernel(h, mpcb_kernel_dyn<3>, a, lds);
+    else if (n <= 5) rc = launch_kernel(h, mpcb_kernel_dyn<5>, a, lds);
+    else rc = launch_kernel(h, mpcb_kernel_dyn<8>, a, lds);
+  } else if (h->cfg.obs_mode == MPCB_OBS_DCBF && h->cfg.gamma < 1.0 - 1e-12 && n > 0) {   // general-gamma CBF rows
+    if (n == 1) rc = launch_kernel(h, mpcb_kernel_kin<1, true>, a, lds);
+    else if (n <= 3) rc = launch_kernel(h, mpcb_kernel_kin<3, true>, a, lds);
+    else rc = launch_kernel(h, mpcb_kernel_kin<8, true>, a, lds);
+  } else if (n == 0) rc = launch_kernel(h, mpcb_kernel_kin<0>, a, lds);
+  else if (n == 1) rc = launch_kernel(h, mpcb_kernel_kin<1>, a, lds);
+  else if (n <= 3) rc = launch_kernel(h, mpcb_kernel_kin<3>, a, lds);
+  else if (n <= 5) rc = launch_kernel(h, mpcb_kernel_kin<5>, a, lds);
+  else rc = launch_kernel(h, mpcb_kernel_kin<8>, a, lds);
+  if (rc != MPCB_OK) return rc;
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipEventRecord(evp.second, h->stream));
+  h->ev_head = (h->ev_head + 1) % mpcb_handle::EV_RING; ++h->ev_pending;
   return MPCB_OK;
 }
 
@@ -247,16 +271,35 @@ int ensure_scratch(mpcb_handle* h, size_t bytes) {
   return MPCB_OK;
 }
 
+// Sub-allocation of the handle's scratch buffer.  The SAME sequence of take() calls runs twice: first with base = NULL to
+// learn the size (so the size formula cannot drift from the carving), then with the allocated base.
 struct Carve {
   char* base; size_t off = 0;
-  template <class T> T* take(size_t n) { off = (off + 255) & ~size_t(255); T* p = (T*)(base + off); off += n * sizeof(T); return p; }
+  template <class T> T* take(size_t n) { off = (off + 255) & ~size_t(255); T* p = base ? (T*)(base + off) : nullptr; off += n * sizeof(T); return p; }
+  size_t bytes() const { return off + 256; }
 };
+
+// one launch of the solve over B instances, everything resident on the handle's device, asynchronous on its stream
+int solve_on_device(mpcb_handle* h, int32_t B, const double* d_x0, const double* d_xs, const double* d_obs, int32_t obs_kind,
+                    const double* d_z0, double* d_z, double* d_obj, int32_t* d_status, int32_t* d_iters, int32_t st_stride,
+                    double* d_kkt, double* d_lam_g, double* d_lam_x) {
+  if (B < 0 || !d_x0 || !d_xs || !d_z) return fail(h, MPCB_E_INVALID, "B < 0 or a required pointer is NULL");
+  if (h->cfg.n_obs > 0 && !d_obs) return fail(h, MPCB_E_INVALID, "n_obs = %d but obs is NULL", h->cfg.n_obs);
+  if (obs_kind != MPCB_OBSIN_STATIC && obs_kind != MPCB_OBSIN_PREDICTED) return fail(h, MPCB_E_INVALID, "unknown obs_kind %d", obs_kind);
+  HIP_TRY(h, hipSetDevice(h->device));
+  MpcbKArgs a;
+  a.cfg = h->cfg; a.B = B; a.nz = h->nz; a.ng = h->ng; a.obs_kind = obs_kind;
+  a.want_mult = (d_lam_g || d_lam_x) ? 1 : 0; a.trace_instance = -1; a.trace = nullptr; a.st_stride = st_stride;
+  a.x0 = d_x0; a.xs = d_xs; a.obs = d_obs; a.z0 = d_z0;
+  a.z = d_z; a.obj = d_obj; a.kkt = d_kkt; a.lam_g = d_lam_g; a.lam_x = d_lam_x; a.status = d_status; a.iters = d_iters;
+  return launch_solve(h, a);
+}
 
 }  // namespace
 
 extern "C" {
 
-const char* mpcb_version(void) { return "mpcbatch 0.1 (gfx950, abi 1)"; }
+const char* mpcb_version(void) { return "mpcbatch 0.2 (gfx950, abi 2)"; }
 
 int mpcb_default_config(mpcb_config* cfg, int32_t model, int32_t N, double T) {
   if (!cfg || (model != MPCB_MODEL_KIN && model != MPCB_MODEL_DYN)) return MPCB_E_INVALID;
@@ -265,7 +308,7 @@ int mpcb_default_config(mpcb_config* cfg, int32_t model, int32_t N, double T) {
   c.struct_size = sizeof(mpcb_config);
   c.model = model; c.N = N; c.T = T; c.gamma = 1.0;
   c.obs_mode = MPCB_OBS_KEEPOUT; c.max_iter = 100;                       // kin.py:252
-  c.mu_strategy = MPCB_MU_MONOTONE; c.init_rollout = 1;
+  c.mu_strategy = MPCB_MU_MONOTONE; c.init_rollout = 1; c.integrator = MPCB_INT_EULER; c.restoration = 1;
   const double rad = M_PI / 180.0;
   for (int i = 0; i < MPCB_NX_MAX; ++i) { c.x_lo[i] = -INF; c.x_hi[i] = INF; }
   // mpc_parameters.yaml: kinematics_constraints / dynamics_constraints / vehicle_params / tire_params
@@ -335,6 +378,7 @@ int mpcb_destroy(mpcb_handle* h) {
   if (!h) return MPCB_OK;
   (void)hipSetDevice(h->device);
   collect_timing(h);
+  for (auto& p : h->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   if (h->d_buf) (void)hipFree(h->d_buf);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -407,16 +451,7 @@ int mpcb_solve_device(mpcb_handle* h, int32_t B, const double* d_x0, const doubl
                       const double* d_z0, double* d_z, double* d_obj, int32_t* d_status, int32_t* d_iters, double* d_kkt,
                       double* d_lam_g, double* d_lam_x, int32_t sync) {
   if (!h) return MPCB_E_INVALID;
-  if (B < 0 || !d_x0 || !d_xs || !d_z) return fail(h, MPCB_E_INVALID, "B < 0 or a required pointer is NULL");
-  if (h->cfg.n_obs > 0 && !d_obs) return fail(h, MPCB_E_INVALID, "n_obs = %d but obs is NULL", h->cfg.n_obs);
-  if (obs_kind != MPCB_OBSIN_STATIC && obs_kind != MPCB_OBSIN_PREDICTED) return fail(h, MPCB_E_INVALID, "unknown obs_kind %d", obs_kind);
-  HIP_TRY(h, hipSetDevice(h->device));
-  MpcbKArgs a;
-  a.cfg = h->cfg; a.B = B; a.nz = h->nz; a.ng = h->ng; a.obs_kind = obs_kind;
-  a.want_mult = (d_lam_g || d_lam_x) ? 1 : 0; a.trace_instance = -1; a.trace = nullptr;
-  a.x0 = d_x0; a.xs = d_xs; a.obs = d_obs; a.z0 = d_z0;
-  a.z = d_z; a.obj = d_obj; a.kkt = d_kkt; a.lam_g = d_lam_g; a.lam_x = d_lam_x; a.status = d_status; a.iters = d_iters;
-  int rc = launch_solve(h, a);
+  int rc = solve_on_device(h, B, d_x0, d_xs, d_obs, obs_kind, d_z0, d_z, d_obj, d_status, d_iters, 1, d_kkt, d_lam_g, d_lam_x);
   if (rc != MPCB_OK) return rc;
   if (sync) HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MPCB_OK;
@@ -431,21 +466,23 @@ int mpcb_solve(mpcb_handle* h, int32_t B, const double* x0, const double* xs, co
   HIP_TRY(h, hipSetDevice(h->device));
   const int nx = h->nx, nz = h->nz, ng = h->ng, N = h->cfg.N;
   const size_t n_obs_d = (size_t)B * h->cfg.n_obs * 6 * (obs_kind == MPCB_OBSIN_PREDICTED ? N + 1 : 1);
-  const size_t need = ((size_t)B * (2 * nx + 2 * nz + 1 + 4 + (lam_g ? ng : 0) + (lam_x ? nz : 0)) + n_obs_d) * 8 + (size_t)B * 8 + 4096 * 4;
-  int rc = ensure_scratch(h, need);
-  if (rc != MPCB_OK) return rc;
-  Carve cv{(char*)h->d_buf};
-  double* d_x0 = cv.take<double>((size_t)B * nx);
-  double* d_xs = cv.take<double>((size_t)B * nx);
-  double* d_obs = n_obs_d ? cv.take<double>(n_obs_d) : nullptr;
-  double* d_z0 = z0 ? cv.take<double>((size_t)B * nz) : nullptr;
-  double* d_z = cv.take<double>((size_t)B * nz);
-  double* d_obj = cv.take<double>(B);
-  double* d_kkt = cv.take<double>((size_t)B * 4);
-  double* d_lg = lam_g ? cv.take<double>((size_t)B * ng) : nullptr;
-  double* d_lx = lam_x ? cv.take<double>((size_t)B * nz) : nullptr;
-  int32_t* d_st = cv.take<int32_t>(B);
-  int32_t* d_it = cv.take<int32_t>(B);
+  double *d_x0, *d_xs, *d_obs, *d_z0, *d_z, *d_obj, *d_kkt, *d_lg, *d_lx; int32_t *d_st, *d_it;
+  auto carve = [&](Carve& cv) {
+    d_x0 = cv.take<double>((size_t)B * nx);
+    d_xs = cv.take<double>((size_t)B * nx);
+    d_obs = n_obs_d ? cv.take<double>(n_obs_d) : nullptr;
+    d_z0 = z0 ? cv.take<double>((size_t)B * nz) : nullptr;
+    d_z = cv.take<double>((size_t)B * nz);
+    d_obj = cv.take<double>(B);
+    d_kkt = cv.take<double>((size_t)B * 4);
+    d_lg = lam_g ? cv.take<double>((size_t)B * ng) : nullptr;
+    d_lx = lam_x ? cv.take<double>((size_t)B * nz) : nullptr;
+    d_st = cv.take<int32_t>(B);
+    d_it = cv.take<int32_t>(B);
+  };
+  { Carve dry{nullptr}; carve(dry); int rc = ensure_scratch(h, dry.bytes()); if (rc != MPCB_OK) return rc; }
+  { Carve cv{(char*)h->d_buf}; carve(cv); }
+  int rc = MPCB_OK;
   hipStream_t s = h->stream;
   HIP_TRY(h, hipMemcpyAsync(d_x0, x0, (size_t)B * nx * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(h, hipMemcpyAsync(d_xs, xs, (size_t)B * nx * 8, hipMemcpyHostToDevice, s));
@@ -472,14 +509,17 @@ int mpcb_solve_trace(mpcb_handle* h, const double* x0, const double* xs, const d
   const int nx = h->nx, nz = h->nz, N = h->cfg.N;
   const size_t n_obs_d = (size_t)h->cfg.n_obs * 6 * (obs_kind == MPCB_OBSIN_PREDICTED ? N + 1 : 1);
   const size_t n_tr = (size_t)(h->cfg.max_iter + 1) * 8;
-  int rc = ensure_scratch(h, (2 * nx + 2 * nz + n_obs_d + n_tr + 64) * 8 + 8192);
-  if (rc != MPCB_OK) return rc;
-  Carve cv{(char*)h->d_buf};
-  double* d_x0 = cv.take<double>(nx); double* d_xs = cv.take<double>(nx);
-  double* d_obs = n_obs_d ? cv.take<double>(n_obs_d) : nullptr;
-  double* d_z0 = z0 ? cv.take<double>(nz) : nullptr;
-  double* d_z = cv.take<double>(nz); double* d_tr = cv.take<double>(n_tr);
-  int32_t* d_st = cv.take<int32_t>(1); int32_t* d_it = cv.take<int32_t>(1);
+  double *d_x0, *d_xs, *d_obs, *d_z0, *d_z, *d_tr; int32_t *d_st, *d_it;
+  auto carve = [&](Carve& cv) {
+    d_x0 = cv.take<double>(nx); d_xs = cv.take<double>(nx);
+    d_obs = n_obs_d ? cv.take<double>(n_obs_d) : nullptr;
+    d_z0 = z0 ? cv.take<double>(nz) : nullptr;
+    d_z = cv.take<double>(nz); d_tr = cv.take<double>(n_tr);
+    d_st = cv.take<int32_t>(1); d_it = cv.take<int32_t>(1);
+  };
+  { Carve dry{nullptr}; carve(dry); int rc = ensure_scratch(h, dry.bytes()); if (rc != MPCB_OK) return rc; }
+  { Carve cv{(char*)h->d_buf}; carve(cv); }
+  int rc = MPCB_OK;
   hipStream_t s = h->stream;
   HIP_TRY(h, hipMemcpyAsync(d_x0, x0, nx * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(h, hipMemcpyAsync(d_xs, xs, nx * 8, hipMemcpyHostToDevice, s));
@@ -487,7 +527,7 @@ int mpcb_solve_trace(mpcb_handle* h, const double* x0, const double* xs, const d
   if (d_z0) HIP_TRY(h, hipMemcpyAsync(d_z0, z0, nz * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(h, hipMemsetAsync(d_tr, 0, n_tr * 8, s));
   MpcbKArgs a;
-  a.cfg = h->cfg; a.B = 1; a.nz = nz; a.ng = h->ng; a.obs_kind = obs_kind; a.want_mult = 0; a.trace_instance = 0; a.trace = d_tr;
+  a.cfg = h->cfg; a.B = 1; a.nz = nz; a.ng = h->ng; a.obs_kind = obs_kind; a.want_mult = 0; a.trace_instance = 0; a.trace = d_tr; a.st_stride = 1;
   a.x0 = d_x0; a.xs = d_xs; a.obs = d_obs; a.z0 = d_z0; a.z = d_z; a.obj = nullptr; a.kkt = nullptr; a.lam_g = nullptr; a.lam_x = nullptr;
   a.status = d_st; a.iters = d_it;
   rc = launch_solve(h, a);
@@ -501,40 +541,40 @@ int mpcb_solve_trace(mpcb_handle* h, const double* x0, const double* xs, const d
 }
 
 int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps, const double* x0, const double* xs, double* obs_state, int32_t obs_motion,
-                     double* x_hist, double* u_hist, int32_t* status_hist, int32_t* iters_hist) {
+                     int32_t flags, double* x_hist, double* u_hist, int32_t* status_hist, int32_t* iters_hist) {
   if (!h) return MPCB_E_INVALID;
   if (B < 0 || steps < 0 || !x0 || !xs) return fail(h, MPCB_E_INVALID, "B < 0, steps < 0 or a required pointer is NULL");
   if (h->cfg.n_obs > 0 && !obs_state) return fail(h, MPCB_E_INVALID, "n_obs = %d but obs_state is NULL", h->cfg.n_obs);
   if (obs_motion < MPCB_OBSMOVE_STATIC || obs_motion > MPCB_OBSMOVE_CURRENT) return fail(h, MPCB_E_INVALID, "unknown obs_motion %d", obs_motion);
+  if (flags & ~(MPCB_CL_HOLD_ON_FAILURE | MPCB_CL_ADVANCE_FIRST_ONLY)) return fail(h, MPCB_E_INVALID, "unknown flags 0x%x", flags);
   const int predict = obs_motion == MPCB_OBSMOVE_PREDICTED;
   if (B == 0 || steps == 0) return MPCB_OK;
   HIP_TRY(h, hipSetDevice(h->device));
   const int nx = h->nx, nz = h->nz, N = h->cfg.N, no = h->cfg.n_obs;
   const size_t n_traj = predict ? (size_t)B * no * (N + 1) * 6 : 0;
-  const size_t need = ((size_t)B * (2 * nx + 2 * nz + no * 6 + (size_t)(steps + 1) * nx + (size_t)steps * 2) + n_traj) * 8 +
-                      (size_t)B * steps * 8 + 8192 * 4;
-  int rc = ensure_scratch(h, need);
-  if (rc != MPCB_OK) return rc;
-  Carve cv{(char*)h->d_buf};
-  double* d_x0 = cv.take<double>((size_t)B * nx);
-  double* d_xs = cv.take<double>((size_t)B * nx);
-  double* d_obs = no ? cv.take<double>((size_t)B * no * 6) : nullptr;
-  double* d_traj = n_traj ? cv.take<double>(n_traj) : nullptr;
-  double* d_z0 = cv.take<double>((size_t)B * nz);
-  double* d_z = cv.take<double>((size_t)B * nz);
-  double* d_xh = cv.take<double>((size_t)B * (steps + 1) * nx);
-  double* d_uh = cv.take<double>((size_t)B * steps * 2);
-  int32_t* d_st = cv.take<int32_t>((size_t)B * steps);
-  int32_t* d_it = cv.take<int32_t>((size_t)B * steps);
+  double *d_x0, *d_xs, *d_obs, *d_traj, *d_z0, *d_z, *d_xh, *d_uh; int32_t *d_st, *d_it;
+  auto carve = [&](Carve& cv) {
+    d_x0 = cv.take<double>((size_t)B * nx);
+    d_xs = cv.take<double>((size_t)B * nx);
+    d_obs = no ? cv.take<double>((size_t)B * no * 6) : nullptr;
+    d_traj = n_traj ? cv.take<double>(n_traj) : nullptr;
+    d_z0 = cv.take<double>((size_t)B * nz);
+    d_z = cv.take<double>((size_t)B * nz);
+    d_xh = cv.take<double>((size_t)B * (steps + 1) * nx);
+    d_uh = cv.take<double>((size_t)B * steps * 2);
+    d_st = cv.take<int32_t>((size_t)B * steps);
+    d_it = cv.take<int32_t>((size_t)B * steps);
+  };
+  { Carve dry{nullptr}; carve(dry); int rc = ensure_scratch(h, dry.bytes()); if (rc != MPCB_OK) return rc; }
+  { Carve cv{(char*)h->d_buf}; carve(cv); }
   hipStream_t s = h->stream;
   HIP_TRY(h, hipMemcpyAsync(d_x0, x0, (size_t)B * nx * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(h, hipMemcpyAsync(d_xs, xs, (size_t)B * nx * 8, hipMemcpyHostToDevice, s));
   if (d_obs) HIP_TRY(h, hipMemcpyAsync(d_obs, obs_state, (size_t)B * no * 6 * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(h, hipMemsetAsync(d_z0, 0, (size_t)B * nz * 8, s));                  // u0 = 0, next_states = 0 (main_cbf_kin_c_sim.py:47-50)
   HIP_TRY(h, hipMemcpy2DAsync(d_xh, (size_t)(steps + 1) * nx * 8, d_x0, (size_t)nx * 8, (size_t)nx * 8, B, hipMemcpyDeviceToDevice, s));
-  // the per-step status / iteration columns are strided: solve writes into a compact column, then scatter
-  int32_t* d_stc = cv.take<int32_t>(B);
-  int32_t* d_itc = cv.take<int32_t>(B);
+  const int move = obs_motion == MPCB_OBSMOVE_STATIC ? 0 : (flags & MPCB_CL_ADVANCE_FIRST_ONLY) ? 2 : 1;
+  const int hold = (flags & MPCB_CL_HOLD_ON_FAILURE) ? 1 : 0;
   for (int t = 0; t < steps; ++t) {
     const double* obs_in = d_obs; int kind = MPCB_OBSIN_STATIC;
     if (predict && no) {
@@ -542,12 +582,15 @@ int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps, const double* x0,
       hipLaunchKernelGGL(mpcb_predict_obs, dim3((total + 255) / 256), dim3(256), 0, s, total, N, h->cfg.T, d_obs, d_traj);
       obs_in = d_traj; kind = MPCB_OBSIN_PREDICTED;
     }
-    rc = mpcb_solve_device(h, B, d_x0, d_xs, obs_in, kind, d_z0, d_z, nullptr, d_stc, d_itc, nullptr, nullptr, nullptr, 0);
+    // the solve kernel writes status / iters of step t straight into column t of the [B, steps] histories
+    int rc = solve_on_device(h, B, d_x0, d_xs, obs_in, kind, d_z0, d_z, nullptr, d_st + t, d_it + t, steps, nullptr, nullptr, nullptr);
     if (rc != MPCB_OK) return rc;
-    HIP_TRY(h, hipMemcpy2DAsync(d_st + t, (size_t)steps * 4, d_stc, 4, 4, B, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(h, hipMemcpy2DAsync(d_it + t, (size_t)steps * 4, d_itc, 4, 4, B, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(mpcb_advance, dim3((B + 127) / 128), dim3(128), 0, s, h->cfg, B, nx, nz, d_z, d_x0, d_z0,
-                       d_obs, d_xh, d_uh, t, steps, obs_motion != MPCB_OBSMOVE_STATIC ? 1 : 0);
+    if (nx == 6)
+      hipLaunchKernelGGL(mpcb_advance<6>, dim3((B + 127) / 128), dim3(128), 0, s, h->cfg, B, nz, d_z, d_x0, d_z0, d_obs, d_xh, d_uh,
+                         d_st + t, steps, t, steps, move, hold);
+    else
+      hipLaunchKernelGGL(mpcb_advance<4>, dim3((B + 127) / 128), dim3(128), 0, s, h->cfg, B, nz, d_z, d_x0, d_z0, d_obs, d_xh, d_uh,
+                         d_st + t, steps, t, steps, move, hold);
     HIP_TRY(h, hipGetLastError());
   }
   if (x_hist) HIP_TRY(h, hipMemcpyAsync(x_hist, d_xh, (size_t)B * (steps + 1) * nx * 8, hipMemcpyDeviceToHost, s));

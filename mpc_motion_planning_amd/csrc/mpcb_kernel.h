@@ -32,6 +32,7 @@ using std::isfinite;
 struct MpcbKArgs {
   mpcb_config cfg;
   int32_t B, nz, ng, obs_kind, want_mult, trace_instance;
+  int32_t st_stride;   // status / iters of instance b go to index b * st_stride (the closed loop writes its [B, steps] histories directly)
   const double *x0, *xs, *obs, *z0;
   double *z, *obj, *kkt, *lam_g, *lam_x;
   int32_t *status, *iters;
@@ -1020,8 +1021,8 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   for (int i = lo; i < nz; i += 64) a.z[(size_t)b * nz + i] = zbuf[i];
   if (lo == 0) {
     if (a.obj) a.obj[b] = fval;
-    if (a.status) a.status[b] = status;
-    if (a.iters) a.iters[b] = iters;
+    if (a.status) a.status[(size_t)b * a.st_stride] = status;
+    if (a.iters) a.iters[(size_t)b * a.st_stride] = iters;
     if (a.kkt) { double* q = a.kkt + (size_t)b * 4; q[0] = err0; q[1] = e_prim; q[2] = e_dual / os; q[3] = mu; }
   }
   if (a.want_mult && a.lam_x) {

@@ -18,6 +18,33 @@ def load_config(config_file):
         return yaml.safe_load(fh)
 
 
+def get_config_path(config_file):
+    """Full path of a configuration file that sits next to the package's own copy (helpers.py:26-38 of the reference resolves
+    against the directory of helpers.py; here that directory is the package's sim/ folder, where mpc_parameters.yaml ships)."""
+    return os.path.join(_PKG_DIR, "sim", config_file)
+
+
+def validate_config(config):
+    """True when every section the classes read is present.  The reference's version (helpers.py:40-55) asks for a section
+    `velocity_constraints` that its own YAML does not have and is never called; this one checks the sections that are used."""
+    needed = ("mpc_params", "vehicle_params", "tire_params", "kinematics_constraints", "dynamics_constraints")
+    missing = [k for k in needed if k not in config]
+    for k in missing:
+        print("configuration lacks the section '%s'" % k)
+    return not missing
+
+
+def print_config(config):
+    """Dump of the parsed YAML, section by section (helpers.py:57-68)."""
+    for section, values in config.items():
+        print("\n%s:" % section)
+        if isinstance(values, dict):
+            for key, value in values.items():
+                print("  %s: %s" % (key, value))
+        else:
+            print("  %s" % (values,))
+
+
 def find_params_file(name=PARAMS_FILE):
     if os.path.exists(name):
         return name

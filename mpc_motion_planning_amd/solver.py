@@ -142,10 +142,13 @@ class BatchSolver:
         check(lib().mpcb_solve_trace(self._h, dptr(x0), dptr(xs), dptr(obs), kind, dptr(z0), dptr(z), iptr(st), iptr(it), dptr(tr)), self._h)
         return dict(z=z[0], status=int(st[0]), iters=int(it[0]), trace=tr[: int(it[0]) + 1])
 
-    def closed_loop(self, x0, xs, obs_state=None, steps=80, obs_motion=_abi.OBSMOVE_STATIC):
+    def closed_loop(self, x0, xs, obs_state=None, steps=80, obs_motion=_abi.OBSMOVE_STATIC, hold_on_failure=False,
+                    advance_first_only=False):
         """Receding-horizon loop on the device (main_cbf_kin_c_sim.py:87-123).  obs_motion: OBSMOVE_STATIC (obstacles fixed,
         main_cbf_kin_c_sim.py), OBSMOVE_PREDICTED (constant-velocity obstacles predicted per solve and advanced per step,
         main_cbf_kin_c_sim_pre.py), OBSMOVE_CURRENT (advanced, no prediction).
+        hold_on_failure: a step whose solve fails applies the previous plan (hold-and-shift) instead of the failed iterate.
+        advance_first_only: only obstacle 0 moves between steps (main_cbf_kin_c_sim_pre.py:106).
         Returns dict(x_hist, u_hist, status, iters, obs_state)."""
         x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, dtype=np.float64)))
         xs = np.ascontiguousarray(np.atleast_2d(np.asarray(xs, dtype=np.float64)))
@@ -155,7 +158,8 @@ class BatchSolver:
             ob = np.array(obs_state, dtype=np.float64).reshape(B, self.cfg.n_obs, 6).copy()
         xh = np.empty((B, steps + 1, self.nx)); uh = np.empty((B, steps, 2))
         st = np.empty((B, steps), np.int32); it = np.empty((B, steps), np.int32)
-        check(lib().mpcb_closed_loop(self._h, B, steps, dptr(x0), dptr(xs), dptr(ob), int(obs_motion), dptr(xh), dptr(uh),
+        flags = (_abi.CL_HOLD_ON_FAILURE if hold_on_failure else 0) | (_abi.CL_ADVANCE_FIRST_ONLY if advance_first_only else 0)
+        check(lib().mpcb_closed_loop(self._h, B, steps, dptr(x0), dptr(xs), dptr(ob), int(obs_motion), flags, dptr(xh), dptr(uh),
                                      iptr(st), iptr(it)), self._h)
         return dict(x_hist=xh, u_hist=uh, status=st, iters=it, obs_state=ob)
 

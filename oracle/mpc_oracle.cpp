@@ -431,12 +431,6 @@ struct Solver {
       }
     }
     mu = c.mu_init; tau = std::max(o.tau_min, 1.0 - mu);
-    if (c.mu_strategy == MPCB_MU_ADAPTIVE || std::getenv("MPCO_CENTER")) {   // centred start: v = mu0 / slack
-      for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) {
-        if (it.hasL) it.vL = mu / (it.s - it.L);
-        if (it.hasU) it.vU = mu / (it.U - it.s);
-      });
-    }
     return true;
   }
 
@@ -805,15 +799,6 @@ struct Solver {
     }
   }
 
-  double avg_compl(double a_pr = 0, double a_du = 0) {
-    double sum = 0; int n = 0;
-    for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) {
-      if (it.hasL) { sum += (it.s - it.L + a_pr * it.ds) * (it.vL + a_du * it.dvL); ++n; }
-      if (it.hasU) { sum += (it.U - it.s - a_pr * it.ds) * (it.vU + a_du * it.dvU); ++n; }
-    });
-    return n ? sum / n : 0.0;
-  }
-
   // ----- main loop ------------------------------------------------------------------------------------------
   void solve() {
     eval_point();
@@ -828,58 +813,20 @@ struct Solver {
       if (!factorize()) { status = MPCB_ST_NUMERIC; break; }
 
       double a_pr, a_du, alpha = 0, dphi = 0; bool armijo_type = false;
-      if (c.mu_strategy == MPCB_MU_MONOTONE) {
-        // barrier parameter update (monotone, Fiacco-McCormick)
-        for (;;) {
-          Err em = kkt_error(mu);
-          if (Emu(em) <= o.kappa_eps * mu && mu > mu_floor) {
-            mu = std::max(mu_floor, std::min(o.kappa_mu * mu, std::pow(mu, o.theta_mu)));
-            tau = std::max(o.tau_min, 1.0 - mu);
-            filter.clear();
-          } else break;
-        }
-        set_targets(mu);
-        solve_direction();
-        step_lengths(tau, a_pr, a_du);
-        dphi = dir_deriv(mu);
-        alpha = line_search(a_pr, mu, dphi, armijo_type);
-      } else {
-        // Mehrotra probing: affine step -> centring sigma -> corrector.  mu never increases.
-        const double mu_cur = avg_compl();
-        set_targets(0.0);
-        solve_direction();
-        double aa_pr, aa_du; step_lengths(1.0, aa_pr, aa_du);
-        const double mu_aff = avg_compl(aa_pr, aa_du);
-        double sigma = std::pow(std::max(0.0, mu_aff / mu_cur), 3.0);
-        sigma = std::min(1.0, std::max(sigma, 1e-8));
-        double mu_t = std::max(mu_floor, sigma * mu_cur);
-        {
-          static const double kinf = std::getenv("MPCO_KINF") ? std::atof(std::getenv("MPCO_KINF")) : 0.0;
-          double einf = std::max(e0.dual / e0.sd, e0.prim);
-          mu_t = std::max(mu_t, kinf * einf);
-        }
-        if (debug) std::fprintf(stderr, "      mu_cur %.3e mu_aff %.3e sigma %.3e aa_pr %.3e aa_du %.3e\n", mu_cur, mu_aff, sigma, aa_pr, aa_du);
-        for (int attempt = 0; attempt < 4; ++attempt) {
-          if (attempt == 0) {
-            for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) {
-              static const double cc = std::getenv("MPCO_CORR") ? std::atof(std::getenv("MPCO_CORR")) : 1e30;
-              double cL = std::max(-cc * mu_t, std::min(cc * mu_t, -it.ds * it.dvL));
-              double cU = std::max(-cc * mu_t, std::min(cc * mu_t, it.ds * it.dvU));
-              it.tL = mu_t + cL;      // second-order term from the predictor
-              it.tU = mu_t + cU;
-            });
-          } else set_targets(mu_t);               // plain centring step
-          solve_direction();
-          tau = std::max(o.tau_min, 1.0 - mu_t);
-          step_lengths(tau, a_pr, a_du);
-          dphi = dir_deriv(mu_t);
+      // barrier parameter update (monotone, Fiacco-McCormick)
+      for (;;) {
+        Err em = kkt_error(mu);
+        if (Emu(em) <= o.kappa_eps * mu && mu > mu_floor) {
+          mu = std::max(mu_floor, std::min(o.kappa_mu * mu, std::pow(mu, o.theta_mu)));
+          tau = std::max(o.tau_min, 1.0 - mu);
           filter.clear();
-          alpha = line_search(a_pr, mu_t, dphi, armijo_type);
-          if (alpha > 0) break;
-          if (attempt >= 1) mu_t = std::min(1e5, 10.0 * std::max(mu_t, mu_cur));   // re-centre harder
-        }
-        mu = mu_t;
+        } else break;
       }
+      set_targets(mu);
+      solve_direction();
+      step_lengths(tau, a_pr, a_du);
+      dphi = dir_deriv(mu);
+      alpha = line_search(a_pr, mu, dphi, armijo_type);
       if (debug) std::fprintf(stderr, "it %3d mu %.2e E0 %.3e th %.3e f %.8e a_pr %.3e a %.3e a_du %.3e dw %.1e dphi %.2e |F|=%zu\n",
                               iters, mu, err0, theta, fval, a_pr, alpha, a_du, dw_used, dphi, filter.size());
       if (debug) {

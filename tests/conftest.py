@@ -29,3 +29,15 @@ def gpu_solver_factory():
 
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture
+def yaml_horizon3(tmp_path, monkeypatch):
+    """BASELINE's N = 30: the package's mpc_parameters.yaml (the reference's values, horizon 5 -> N_p = 50) with horizon: 3,
+    placed in the current working directory, which is where the reference's classes look for it (kin.py:7,11)."""
+    src = os.path.join(ROOT, "mpc_motion_planning_amd", "sim", "mpc_parameters.yaml")
+    text = open(src).read().replace("horizon: 5", "horizon: 3")
+    assert "horizon: 3" in text
+    (tmp_path / "mpc_parameters.yaml").write_text(text)
+    monkeypatch.chdir(tmp_path)
+    return tmp_path

@@ -6,7 +6,22 @@ from mpc_motion_planning_amd import MPC_CBF_optimize_kin, MPC_CBF_optimize_kin_p
 from mpc_motion_planning_amd.Obs_prediction import obs_prediction
 
 
-def test_kin_constructor_and_bounds_lists():
+def test_shipped_yaml_is_the_reference_problem():
+    """The packaged YAML carries the reference's values (mpc_parameters.yaml:4-9): horizon 5 -> N_p = 50, nz = 304, 303 rows
+    with one obstacle, and the 'Flase' spelling that selects the fixed grid."""
+    m = MPC_CBF_optimize_kin.MPC_optimize()
+    assert (m.N_p, m.T_S, m.num_states, m.num_controls) == (50, 0.1, 4, 2)
+    assert m.is_variable_time == "Flase" and len(m.t_vector) == 51
+    lbg, ubg, lbx, ubx = m.initialize_constraints(np.array([[50, 3.5, 0, 8, 4.8, 1.8]]))
+    assert len(lbx) == 304 and len(lbg) == 204 + 49 + 50
+    tr = m.generate_ref_path(np.array([0, 3, 0, 15.0]).reshape(-1, 1), np.array([400, 3.5, 0, 30.0]).reshape(-1, 1))
+    assert tr.shape == (51, 4) and tr[0, 0] == 0 and tr[29, 0] == pytest.approx(90) and tr[-1, 0] == pytest.approx(150) and tr[-1, 1] == pytest.approx(3.5)
+    from mpc_motion_planning_amd import helpers
+    assert helpers.validate_config(m.config) and helpers.get_config_path("mpc_parameters.yaml").endswith("mpc_parameters.yaml")
+    assert not helpers.validate_config({"mpc_params": {}})
+
+
+def test_kin_constructor_and_bounds_lists(yaml_horizon3):
     m = MPC_CBF_optimize_kin.MPC_optimize()
     assert (m.N_p, m.T_S, m.num_states, m.num_controls) == (30, 0.1, 4, 2)
     assert len(m.t_vector) == 31
@@ -26,7 +41,7 @@ def test_kin_constructor_and_bounds_lists():
     assert len(lbg3) == 243
 
 
-def test_kin_pre_and_dyn_bounds():
+def test_kin_pre_and_dyn_bounds(yaml_horizon3):
     m = MPC_CBF_optimize_kin_pre.MPC_optimize()
     tr = obs_prediction([np.array([[50, 3.5, 0, 10, 4.8, 1.8]])], m.T_S, m.N_p)
     lbg, ubg, lbx, ubx = m.initialize_constraints(tr)
@@ -70,7 +85,7 @@ def test_sharding_bounds():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_result_dict_constraint_values_follow_reference_row_order():
+def test_result_dict_constraint_values_follow_reference_row_order(yaml_horizon3):
     """res['g'] is computed on the host in the reference's g order; check it against the independent restatement."""
     from oracle import kkt_check
     from mpc_motion_planning_amd._mpc_base import nlp_constraints
