@@ -29,6 +29,13 @@ __global__ __launch_bounds__(64, MPCB_WAVES_PER_SIMD) void mpcb_kernel_kin(const
   mpcb_solve_kin<NOBS, GEN>(a, (int)blockIdx.x, mpcb_lds);
 }
 
+// restoration pass: main phase + restoration phase; a workgroup whose instance does not need it returns at once
+template <int NOBS, bool GEN = false>
+__global__ __launch_bounds__(64, 1) void mpcb_kernel_kin_resto(const MpcbKArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double mpcb_lds[];
+  mpcb_solve_kin<NOBS, GEN, true>(a, (int)blockIdx.x, mpcb_lds);
+}
+
 template <int NOBS>
 __global__ __launch_bounds__(64, MPCB_WAVES_PER_SIMD) void mpcb_kernel_dyn(const MpcbKArgs a) {
   extern __shared__ __attribute__((aligned(16))) double mpcb_lds[];
@@ -142,7 +149,10 @@ struct mpcb_handle {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;   // EV_RING pairs, created on first use
   int ev_head = 0, ev_pending = 0;                     // next pair to record into; pairs recorded and not yet harvested
   int launches = 0; double total_ms = 0, last_ms = 0;
-  bool lds_attr_set = false;                           // hipFuncAttributeMaxDynamicSharedMemorySize applied to this handle's kernel
+  bool lds_attr_set[2] = {false, false};               // hipFuncAttributeMaxDynamicSharedMemorySize applied to this handle's kernels (first pass, restoration pass)
+  // two-pass solve (cfg.restoration): hand-over records [B][WK_SIZE] and, when the caller passes no status array, the status
+  // column the passes communicate through
+  double* d_work = nullptr; int32_t* d_st_own = nullptr; int work_cap = 0;
 };
 
 namespace {
@@ -185,6 +195,8 @@ int check_cfg(mpcb_handle* h, const mpcb_config* c) {
     return fail(h, MPCB_E_UNSUPPORTED, "MPCB_INT_RK4: the reference's NLP and plant are explicit Euler (kin.py:207); no RK4 mode is built");
   if (c->integrator != MPCB_INT_EULER) return fail(h, MPCB_E_INVALID, "unknown integrator %d", c->integrator);
   if (c->restoration != 0 && c->restoration != 1) return fail(h, MPCB_E_INVALID, "restoration must be 0 or 1");
+  if (c->restoration && c->model == MPCB_MODEL_DYN)
+    return fail(h, MPCB_E_UNSUPPORTED, "the restoration phase is implemented for the kinematic model; set restoration = 0 for MPCB_MODEL_DYN");
   if (std::isfinite(c->x_lo[0]) || std::isfinite(c->x_hi[0]) || std::isfinite(c->x_lo[2]) || std::isfinite(c->x_hi[2]))
     return fail(h, MPCB_E_UNSUPPORTED, "state boxes are supported on y, vx (and vy for the dynamic model) (kin.py:97-105, dyn.py:97-110)");
   if (c->model == MPCB_MODEL_KIN) {
@@ -221,18 +233,38 @@ int collect_timing(mpcb_handle* h) {
 
 template <class K>
 int launch_kernel(mpcb_handle* h, K kernel, const MpcbKArgs& a, size_t lds) {
-  if (lds > 48 * 1024 && !h->lds_attr_set) {   // once per handle: one handle = one device + one kernel instantiation
+  if (lds > 48 * 1024 && !h->lds_attr_set[a.pass]) {   // once per handle and pass: one handle = one device + one NLP structure
     HIP_TRY(h, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    h->lds_attr_set = true;
+    h->lds_attr_set[a.pass] = true;
   }
   hipLaunchKernelGGL(kernel, dim3(a.B), dim3(64), lds, h->stream, a);
   return MPCB_OK;
 }
 
-int launch_solve(mpcb_handle* h, const MpcbKArgs& a) {
+bool two_pass(const mpcb_config& c) { return c.restoration != 0; }
+
+int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in) {
+  MpcbKArgs a = a_in;
   const size_t lds = lds_bytes(h->cfg, h->nz);
   if (lds > 160 * 1024) return fail(h, MPCB_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds);
   if (a.B == 0) return MPCB_OK;
+  a.pass = 0; a.work = nullptr;
+  if (two_pass(h->cfg)) {
+    if (a.B > h->work_cap) {       // grows with the largest batch seen (first call of a given size only)
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      if (h->d_work) HIP_TRY(h, hipFree(h->d_work));
+      if (h->d_st_own) HIP_TRY(h, hipFree(h->d_st_own));
+      h->d_work = nullptr; h->d_st_own = nullptr; h->work_cap = 0;
+      HIP_TRY(h, hipMalloc(&h->d_work, (size_t)a.B * mpcbk::WK_SIZE * sizeof(double)));
+      HIP_TRY(h, hipMalloc(&h->d_st_own, (size_t)a.B * sizeof(int32_t)));
+      h->work_cap = a.B;
+    }
+    a.work = h->d_work;
+    if (!a.status) {                 // the passes communicate through the status column
+      if (a.st_stride != 1) return fail(h, MPCB_E_INVALID, "a strided iteration history needs a status history");
+      a.status = h->d_st_own;
+    }
+  }
   if (h->ev.empty()) {
     h->ev.resize(mpcb_handle::EV_RING);
     for (auto& p : h->ev) { HIP_TRY(h, hipEventCreate(&p.first)); HIP_TRY(h, hipEventCreate(&p.second)); }
@@ -258,6 +290,24 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a) {
   else rc = launch_kernel(h, mpcb_kernel_kin<8>, a, lds);
   if (rc != MPCB_OK) return rc;
   HIP_TRY(h, hipGetLastError());
+  if (two_pass(h->cfg)) {
+    // restoration pass over the same grid: instances that ended the first pass with MPCB_ST_NEEDS_RESTO continue, the others return
+    a.pass = 1;
+    const size_t lds2 = (size_t)mpcbk::layout_kin(h->cfg.N, h->nz, true).total * sizeof(double);
+    if (lds2 > 160 * 1024) return fail(h, MPCB_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds2);
+    const bool gen = h->cfg.obs_mode == MPCB_OBS_DCBF && h->cfg.gamma < 1.0 - 1e-12 && n > 0;
+    if (gen) {
+      if (n == 1) rc = launch_kernel(h, mpcb_kernel_kin_resto<1, true>, a, lds2);
+      else if (n <= 3) rc = launch_kernel(h, mpcb_kernel_kin_resto<3, true>, a, lds2);
+      else rc = launch_kernel(h, mpcb_kernel_kin_resto<8, true>, a, lds2);
+    } else if (n == 0) rc = launch_kernel(h, mpcb_kernel_kin_resto<0>, a, lds2);
+    else if (n == 1) rc = launch_kernel(h, mpcb_kernel_kin_resto<1>, a, lds2);
+    else if (n <= 3) rc = launch_kernel(h, mpcb_kernel_kin_resto<3>, a, lds2);
+    else if (n <= 5) rc = launch_kernel(h, mpcb_kernel_kin_resto<5>, a, lds2);
+    else rc = launch_kernel(h, mpcb_kernel_kin_resto<8>, a, lds2);
+    if (rc != MPCB_OK) return rc;
+    HIP_TRY(h, hipGetLastError());
+  }
   HIP_TRY(h, hipEventRecord(evp.second, h->stream));
   h->ev_head = (h->ev_head + 1) % mpcb_handle::EV_RING; ++h->ev_pending;
   return MPCB_OK;
@@ -308,7 +358,7 @@ int mpcb_default_config(mpcb_config* cfg, int32_t model, int32_t N, double T) {
   c.struct_size = sizeof(mpcb_config);
   c.model = model; c.N = N; c.T = T; c.gamma = 1.0;
   c.obs_mode = MPCB_OBS_KEEPOUT; c.max_iter = 100;                       // kin.py:252
-  c.mu_strategy = MPCB_MU_MONOTONE; c.init_rollout = 1; c.integrator = MPCB_INT_EULER; c.restoration = 1;
+  c.mu_strategy = MPCB_MU_MONOTONE; c.init_rollout = 1; c.integrator = MPCB_INT_EULER; c.restoration = (model == MPCB_MODEL_KIN) ? 1 : 0;
   const double rad = M_PI / 180.0;
   for (int i = 0; i < MPCB_NX_MAX; ++i) { c.x_lo[i] = -INF; c.x_hi[i] = INF; }
   // mpc_parameters.yaml: kinematics_constraints / dynamics_constraints / vehicle_params / tire_params
@@ -380,6 +430,8 @@ int mpcb_destroy(mpcb_handle* h) {
   collect_timing(h);
   for (auto& p : h->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   if (h->d_buf) (void)hipFree(h->d_buf);
+  if (h->d_work) (void)hipFree(h->d_work);
+  if (h->d_st_own) (void)hipFree(h->d_st_own);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return MPCB_OK;

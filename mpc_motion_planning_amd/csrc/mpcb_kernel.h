@@ -33,6 +33,9 @@ struct MpcbKArgs {
   mpcb_config cfg;
   int32_t B, nz, ng, obs_kind, want_mult, trace_instance;
   int32_t st_stride;   // status / iters of instance b go to index b * st_stride (the closed loop writes its [B, steps] histories directly)
+  int32_t pass;        // 0: first pass (main phase; an instance that needs the restoration phase ends with MPCB_ST_NEEDS_RESTO and a
+                       //    hand-over record in `work`); 1: restoration pass (RESTO kernel instantiation, only those instances run)
+  double* work;        // [B][WK_SIZE] hand-over records between the passes (device scratch of the handle), NULL when cfg.restoration == 0
   const double *x0, *xs, *obs, *z0;
   double *z, *obj, *kkt, *lam_g, *lam_x;
   int32_t *status, *iters;
@@ -52,10 +55,23 @@ struct MpcbKArgs {
 #define MPCB_SCHED_FENCE() ((void)0)
 #endif
 
+// internal status between the two passes of a solve; never returned to the caller
+#define MPCB_ST_NEEDS_RESTO 7
+
 namespace mpcbk {
 
 constexpr int NU = 2;
 constexpr int FILTER_MAX = 64;
+// restoration phase (oracle: Solver::restoration()): penalty rho, required reduction of the violation, safety
+// factor of the duality-gap certificate; early entry after TRIG_K accepted steps in a row shorter than TRIG_ALPHA that together
+// reduced theta by less than the factor TRIG_THETA
+constexpr double RS_RHO = 1000.0, RS_KAPPA = 0.5, RS_GAP = 10.0, TRIG_ALPHA = 0.05, TRIG_THETA = 0.8;
+constexpr int TRIG_K = 5;
+// hand-over record of an instance that needs the restoration pass
+constexpr int WK_MU = 0, WK_THMAX = 1, WK_THMIN = 2, WK_ITERS = 3, WK_DW = 4, WK_SIZE = 8;
+// per-node cost table of the RESTO instantiations, [row][64] in LDS (lane = node): scaled weights osc*2*Qc, reference point,
+// osc*2*Rc, control reference, the unscaled weights Qc, Rc, and the rate-cost weights osc*2*DRc, DRc
+enum CostRow { CT_WQ = 0, CT_XR = 4, CT_WR = 8, CT_UR = 10, CT_QQ = 12, CT_RR = 16, CT_WDR = 18, CT_DRR = 20, CT_ROWS = 22 };
 
 // compact stage entries of the kinematic model, variable order of a stage: [x, y, phi, v, dprev, aprev, d, a]
 enum KinEnt {
@@ -80,9 +96,9 @@ constexpr int FWS = 28, FW_KFF = 12, FW_A = 14, FW_D = 20, FW_PAD = 24, WSZ = 72
 // instead of holding ~25 SGPR pairs through the whole solve
 constexpr int CS_WQ = 0, CS_WR = 4, CS_WDR = 6, CS_Q = 8, CS_R = 12, CS_DR = 14, CS_UL = 16, CS_XS = 18, CSZ = 24;
 struct Layout {
-  int ld, ent, Pst, fw, W, cst, filt, zbuf, total;
+  int ld, ent, Pst, fw, W, cst, filt, zbuf, ct, total;
 };
-MPCB_HD Layout layout_kin(int N, int nz) {
+MPCB_HD Layout layout_kin(int N, int nz, bool resto = false) {
   Layout L;
   const int N1 = N + 1;
   L.ld = N1 | 1;
@@ -95,6 +111,7 @@ MPCB_HD Layout layout_kin(int N, int nz) {
   L.ent = o; o += KIN_NENT * L.ld;
   L.zbuf = L.Pst;                    // staging of z rows aliases the Riccati storage (used before / after the loop)
   (void)nz;
+  L.ct = o; if (resto) o += CT_ROWS * 64;
   L.total = o;
   return L;
 }
@@ -168,14 +185,17 @@ constexpr double DW_FIRST = 1e-4, DW_MIN = 1e-20, DW_MAX = 1e40, KW_MINUS = 1.0 
 //   c_i(X_i) = h(X_i + T f(X_i)) - (1 - gamma) h(X_i) >= gamma hmin      (stage-i obstacle in both terms, as the reference writes it)
 // which equals the reference's  gamma h(X_i) + h(X_{i+1}) - h(X_i)  on the feasible set because the position part of the Euler
 // step depends on X_i only.  Its gradient has four entries (x, y, phi, v) and its Hessian fills the state block.
-template <int NOBS, bool GEN = false>
+// RESTO = the instantiation that runs the restoration pass (a.pass == 1): main phase + restoration phase with a run-time phase
+// flag, per-node cost table, elastic obstacle rows.  The RESTO = false instantiation is the lean main phase of the first pass.
+template <int NOBS, bool GEN = false, bool RESTO = false>
 MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   using namespace mpcbk;
-  constexpr int NX = 4, NA = 6, NW = 8, NOB = NOBS > 0 ? NOBS : 1;
+  constexpr int NX = 4, NA = 6, NW = 8, NOB = NOBS > 0 ? NOBS : 1, NEL = RESTO ? NOB : 1;
   const mpcb_config& c = a.cfg;
   const int N = c.N, lane = wv::lane(), k = lane;
   const int nz = a.nz, nobs = c.n_obs;
-  const Layout L = layout_kin(N, nz);
+  if (RESTO && a.status[(size_t)b * a.st_stride] != MPCB_ST_NEEDS_RESTO) return;     // wave-uniform: this instance is done
+  const Layout L = layout_kin(N, nz, RESTO);
   const int ld = L.ld;
   double* ent = lds + L.ent;
   const double T = c.T, il = 1.0 / c.veh_l;
@@ -251,6 +271,16 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     g = wv::uni(wv::max(g));
     os = wv::uni((g > c.max_gradient) ? c.max_gradient / g : 1.0);
   }
+  if (RESTO) {     // restoration pass: the iterate is what the first pass left in z (the scaling above is that of the user's start)
+    wv::sync();
+    for (int i = lane; i < nz; i += 64) zbuf[i] = a.z[(size_t)b * nz + i];
+    wv::sync();
+#pragma unroll
+    for (int i = 0; i < NU; ++i) U[i] = hasu ? zbuf[NU * k + i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) X[i] = isnode ? zbuf[NU * N + NX * k + i] : 0.0;
+    wv::sync();
+  }
   double* cst = lds + L.cst;
   if (lane == 0) {
 #pragma unroll
@@ -259,6 +289,59 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     for (int i = 0; i < NU; ++i) { cst[CS_WR + i] = os * 2 * c.R[i]; cst[CS_WDR + i] = os * 2 * c.DR[i]; cst[CS_R + i] = c.R[i]; cst[CS_DR + i] = c.DR[i]; cst[CS_UL + i] = c.u_last[i]; }
   }
   wv::sync();
+  // The objective of the running phase.  First-pass instantiation: the uniform constants of the block above.  RESTO instantiation:
+  // a per-node table (lane = node, every lane reads and writes only its own column), because the restoration phase replaces
+  // the cost by the proximity term zeta/2 ||D_R (w - w_R)||^2 with per-node weights and reference (oracle: set_resto_cost).
+  double* ct = lds + L.ct;
+  double osc = os;                       // scale of the running phase's objective: os, or 1 in the restoration phase
+  bool rs = false;                       // restoration phase active
+  auto cWQ = [&](int i) { return RESTO ? ct[(CT_WQ + i) * 64 + lane] : cst[CS_WQ + i]; };
+  auto cXS = [&](int i) { return RESTO ? ct[(CT_XR + i) * 64 + lane] : cst[CS_XS + i]; };
+  auto cQQ = [&](int i) { return RESTO ? ct[(CT_QQ + i) * 64 + lane] : cst[CS_Q + i]; };
+  auto cWR = [&](int i) { return RESTO ? ct[(CT_WR + i) * 64 + lane] : cst[CS_WR + i]; };
+  auto cRR = [&](int i) { return RESTO ? ct[(CT_RR + i) * 64 + lane] : cst[CS_R + i]; };
+  auto cUR = [&](int i) { return RESTO ? ct[(CT_UR + i) * 64 + lane] : 0.0; };
+  auto cWDR = [&](int i) { return RESTO ? ct[(CT_WDR + i) * 64 + lane] : cst[CS_WDR + i]; };
+  auto cDRR = [&](int i) { return RESTO ? ct[(CT_DRR + i) * 64 + lane] : cst[CS_DR + i]; };
+  auto write_main_cost = [&]() {         // kin.py:168-205: Q on nodes 0..N-1 (no terminal cost), R, DR; set-point xs, U reference 0
+    if (RESTO) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        ct[(CT_WQ + i) * 64 + lane] = hasu ? os * 2 * c.Q[i] : 0.0; ct[(CT_QQ + i) * 64 + lane] = hasu ? c.Q[i] : 0.0;
+        ct[(CT_XR + i) * 64 + lane] = xs[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        ct[(CT_WR + i) * 64 + lane] = hasu ? os * 2 * c.R[i] : 0.0; ct[(CT_RR + i) * 64 + lane] = hasu ? c.R[i] : 0.0;
+        ct[(CT_UR + i) * 64 + lane] = 0.0;
+        ct[(CT_WDR + i) * 64 + lane] = os * 2 * c.DR[i]; ct[(CT_DRR + i) * 64 + lane] = c.DR[i];
+      }
+    }
+  };
+  // zeta/2 * D^2 (w - w_R)^2 on X_1..X_N and U_0..U_{N-1}, D = 1 / max(1, |w_R|); `fresh` also latches w_R = current (X, U)
+  auto write_resto_cost = [&](double zeta, bool fresh, const double* Xc, const double* Uc) {
+    if (RESTO) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        if (fresh) ct[(CT_XR + i) * 64 + lane] = Xc[i];
+        const double d = 1.0 / fmax(1.0, fabs(ct[(CT_XR + i) * 64 + lane]));
+        const double q = xnode ? 0.5 * zeta * d * d : 0.0;
+        ct[(CT_QQ + i) * 64 + lane] = q; ct[(CT_WQ + i) * 64 + lane] = 2 * q;
+      }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        if (fresh) ct[(CT_UR + i) * 64 + lane] = Uc[i];
+        const double d = 1.0 / fmax(1.0, fabs(ct[(CT_UR + i) * 64 + lane]));
+        const double q = hasu ? 0.5 * zeta * d * d : 0.0;
+        ct[(CT_RR + i) * 64 + lane] = q; ct[(CT_WR + i) * 64 + lane] = 2 * q;
+        ct[(CT_WDR + i) * 64 + lane] = 0.0; ct[(CT_DRR + i) * 64 + lane] = 0.0;
+      }
+    }
+  };
+  write_main_cost();
+  // masks of the cost terms: the table of the RESTO instantiation holds zeros where a term does not exist in the running phase
+  const bool xq = RESTO ? xnode : xcost;                 // stage cost on X_k in the Hessian / gradient
+  const bool xobj = RESTO ? isnode : hasu;               // ... in the objective value (node 0: a constant)
   // pin node 0
   if (k == 0) {
 #pragma unroll
@@ -303,7 +386,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   };
 
   // optional roll-out of X from x0 with the guessed (clipped) controls
-  if (c.init_rollout) {
+  if (!RESTO && c.init_rollout) {
     U[0] = hasu ? fmin(fmax(U[0], c.u_lo[0]), c.u_hi[0]) : 0.0;
     U[1] = hasu ? fmin(fmax(U[1], c.u_lo[1]), c.u_hi[1]) : 0.0;
     double sd, cd; sincos_b(U[0], sd, cd);
@@ -320,16 +403,22 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
 
   // push the start inside the (relaxed) boxes; duals = 1
   Item iU0{1, 1, 0, 0}, iU1{1, 1, 0, 0}, iY{1, 1, 0, 0}, iV{1, 1, 0, 0}, iR{1, 1, 0, 0};
-  if (bu0_on) U[0] = push_in(qU0, U[0], c.bound_push, c.bound_frac);
-  if (bu1_on) U[1] = push_in(qU1, U[1], c.bound_push, c.bound_frac);
-  if (by_on) X[1] = push_in(qY, X[1], c.bound_push, c.bound_frac);
-  if (bv_on) X[3] = push_in(qV, X[3], c.bound_push, c.bound_frac);
+  if (!RESTO) {    // (the restoration pass starts from an interior iterate of the first pass)
+    if (bu0_on) U[0] = push_in(qU0, U[0], c.bound_push, c.bound_frac);
+    if (bu1_on) U[1] = push_in(qU1, U[1], c.bound_push, c.bound_frac);
+    if (by_on) X[1] = push_in(qY, X[1], c.bound_push, c.bound_frac);
+    if (bv_on) X[3] = push_in(qV, X[3], c.bound_push, c.bound_frac);
+  }
   // general rows: slack = row value at the pushed start, pushed inside its own bounds
   double Up0 = wv::shfl(U[0], k - 1), Up1 = wv::shfl(U[1], k - 1);   // U_{k-1}
   double sR = 0, rR = 0;
   if (rr_on) sR = push_in(qR, U[0] - Up0, c.bound_push, c.bound_frac);
   double sO[NOB], vO[NOB], iO[NOB], rO[NOB], gO0[NOB], gO1[NOB], gO2[GEN ? NOB : 1], gO3[GEN ? NOB : 1];
   bool ro_on[NOB];
+  // restoration phase: elastic variables of the obstacle rows  c(w) - s - p + n = 0  and their duals (zero outside it)
+  double eP[NEL], eN[NEL], vP[NEL], vN[NEL];
+#pragma unroll
+  for (int j = 0; j < NEL; ++j) { eP[j] = 0; eN[j] = 0; vP[j] = 0; vN[j] = 0; }
   {
     double s0 = 0, c0 = 1;
     if (GEN) sincos_b(X[2], s0, c0);
@@ -371,7 +460,8 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
 
   // per-lane pieces of an evaluation at (Xa, Ua): defects, row residuals, theta/f/log partial sums.
   // Returns false in a lane whose slack or box distance is not positive.
-  auto eval_lane = [&](const double* Xa, const double* Ua, double sRa, const double* sOa, double s_, double c_, double t_,
+  auto eval_lane = [&](const double* Xa, const double* Ua, double sRa, const double* sOa, const double* pa, const double* na,
+                       double s_, double c_, double t_,
                        double* dfa, double& rRa, double* rOa, double& up0, double& up1, double& th, double& fl, double& prod) {
     bool ok = true;
     const double v = Xa[3];
@@ -391,14 +481,28 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     rRa = 0;
     if (rr_on) { bar(qR, sRa); rRa = (Ua[0] - up0) - sRa; th += fabs(rRa); }
 #pragma unroll
-    for (int j = 0; j < NOBS; ++j) { rOa[j] = 0; if (ro_on[j]) { bar(qO, sOa[j]); rOa[j] = rowval(j, Xa[0], Xa[1], s_, c_, v) - sOa[j]; th += fabs(rOa[j]); } }
-    if (hasu) {   // objective terms of stage k (kin.py:195-205)
+    for (int j = 0; j < NOBS; ++j) {
+      rOa[j] = 0;
+      if (ro_on[j]) {
+        bar(qO, sOa[j]); rOa[j] = rowval(j, Xa[0], Xa[1], s_, c_, v) - sOa[j];
+        if (RESTO && rs) {        // elastic row: residual of c - s - p + n, cost rho (p + n), barrier on p and n
+          const double pj = pa[j], nj = na[j];
+          ok = ok && (pj > 0) && (nj > 0); prod *= pj * nj;
+          rOa[j] -= pj - nj; fl += RS_RHO * (pj + nj);
+        }
+        th += fabs(rOa[j]);
+      }
+    }
+    if (xobj) {   // objective terms of node k (kin.py:195-205; restoration phase: proximity term)
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { const double e = Xa[i] - cst[CS_XS + i]; fl += cst[CS_Q + i] * e * e; }
-      fl += cst[CS_R] * Ua[0] * Ua[0] + cst[CS_R + 1] * Ua[1] * Ua[1];
+      for (int i = 0; i < NX; ++i) { const double e = Xa[i] - cXS(i); fl += cQQ(i) * e * e; }
+    }
+    if (hasu) {
+      const double e0 = Ua[0] - cUR(0), e1 = Ua[1] - cUR(1);
+      fl += cRR(0) * e0 * e0 + cRR(1) * e1 * e1;
       if (k > 0 || c.du0_cost) {
         const double d0 = Ua[0] - (k ? up0 : cst[CS_UL]), d1 = Ua[1] - (k ? up1 : cst[CS_UL + 1]);
-        fl += cst[CS_DR] * d0 * d0 + cst[CS_DR + 1] * d1 * d1;
+        fl += cDRR(0) * d0 * d0 + cDRR(1) * d1 * d1;
       }
     }
     return ok;
@@ -507,22 +611,103 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   const double mu_floor = c.tol / (K_EPS + 1.0);
   double err0 = 0, e_dual = 0, e_prim = 0;
 
+  // restoration-phase state (RESTO instantiation): the main phase's mu and filter bounds while the restoration runs, the entry
+  // pair of the main filter, the violation at entry, iterations inside the phase; `enter` asks the loop top to start the phase
+  double mu_main = 0, tmax_main = 0, tmin_main = 0, fm_theta = 0, fm_phi = 0, th_entry = 0;
+  int rit = 0, slow_run = 0;
+  double slow_theta0 = 0;
+  bool enter = false;
+  double n_el = 0;                       // number of elastic rows (constant of the instance)
+  if (RESTO) {
+    double cnt = 0;
+#pragma unroll
+    for (int j = 0; j < NOBS; ++j) if (ro_on[j]) cnt += 1.0;
+    n_el = wv::uni(wv::sum(cnt));
+  }
+
   if (status != MPCB_ST_INFEASIBLE_X0) {
-    // evaluation at the start point
-    {
+    if (!RESTO) {
+      // evaluation at the start point
       trig(X[2], U[0], sp, cp, td, sec2);
       double th, fl, prod;
-      eval_lane(X, U, sR, sO, sp, cp, td, dfc, rR, rO, Up0, Up1, th, fl, prod);
+      eval_lane(X, U, sR, sO, eP, eN, sp, cp, td, dfc, rR, rO, Up0, Up1, th, fl, prod);
       double sv[3] = {th, fl, log(prod)};
       wv::reduce<3, 0>(sv, nullptr);
       theta = wv::uni(sv[0]); fval = wv::uni(sv[1]); logsum = wv::uni(sv[2]);
       recips();
       row_grads(sp, cp);
+      theta_max = wv::uni(1e4 * fmax(1.0, theta)); theta_min = wv::uni(1e-4 * fmax(1.0, theta));
+    } else {
+      // restoration pass: the iterate is what the first pass left in z, the scalars come from its hand-over record
+      const double* wk = a.work + (size_t)b * WK_SIZE;
+      mu = wv::uni(wk[WK_MU]); tau = fmax(TAU_MIN, 1.0 - mu);
+      theta_max = wv::uni(wk[WK_THMAX]); theta_min = wv::uni(wk[WK_THMIN]);
+      iters = (int)wk[WK_ITERS]; dw_last = wv::uni(wk[WK_DW]);
+      enter = true;
     }
-    theta_max = wv::uni(1e4 * fmax(1.0, theta)); theta_min = wv::uni(1e-4 * fmax(1.0, theta));
 
+    int trips = 0;                       // passes through the loop top, counted or not: the exit every wave reaches
 #pragma clang loop unroll(disable)
-    for (iters = 0;; ++iters) {
+    for (;;) {
+      if (++trips > 3 * c.max_iter + 50) { status = MPCB_ST_RESTO_FAILED; break; }   // (phase changes do not count as iterations)
+      if (RESTO && enter) {
+        // ----- entry into the restoration phase (oracle: Solver::restoration) ------------------------------------------------
+        enter = false;
+        mu_main = mu; tmax_main = theta_max; tmin_main = theta_min;
+        rs = false; osc = os;
+        // slacks of the general rows re-initialised from w as at a fresh start; the entry pair of the main filter is taken there
+        trig(X[2], U[0], sp, cp, td, sec2);
+        Up0 = wv::shfl(U[0], k - 1); Up1 = wv::shfl(U[1], k - 1);
+        if (rr_on) sR = push_in(qR, U[0] - Up0, c.bound_push, c.bound_frac);
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j) if (ro_on[j]) sO[j] = push_in(qO, rowval(j, X[0], X[1], sp, cp, X[3]), c.bound_push, c.bound_frac);
+        double th, fl, prod;
+        eval_lane(X, U, sR, sO, eP, eN, sp, cp, td, dfc, rR, rO, Up0, Up1, th, fl, prod);
+        double vi = fabs(rR);
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j) vi = fmax(vi, fabs(rO[j]));
+        if (hasu) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) vi = fmax(vi, fabs(dfc[i]));
+        }
+        double sv[3] = {th, fl, log(prod)}, mv[1] = {vi};
+        wv::reduce<3, 1>(sv, mv);
+        th_entry = wv::uni(sv[0]);
+        const double phi_entry = os * wv::uni(sv[1]) - mu_main * wv::uni(sv[2]);
+        fm_theta = (1 - G_THETA) * th_entry; fm_phi = phi_entry - G_PHI * th_entry;
+        // the restoration problem: proximity cost around the entry point, elastic obstacle rows, centred duals capped at rho
+        rs = true; osc = 1.0;
+        mu = wv::uni(fmax(mu_main, wv::uni(mv[0]))); tau = fmax(TAU_MIN, 1.0 - mu);
+        write_resto_cost(sqrt(mu), true, X, U);
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
+          const double r0 = rO[j], aa = (mu - RS_RHO * r0) / (2 * RS_RHO);
+          eN[j] = aa + sqrt(aa * aa + mu * r0 / (2 * RS_RHO)); eP[j] = r0 + eN[j];
+          vP[j] = mu / eP[j]; vN[j] = mu / eN[j];
+        }
+        recips();
+        auto centre = [&](const Bnd& q, Item& it) {
+          if (q.hasL) it.vL = fmin(RS_RHO, mu * it.iL);
+          if (q.hasU) it.vU = fmin(RS_RHO, mu * it.iU);
+        };
+        if (bu0_on) centre(qU0, iU0);
+        if (bu1_on) centre(qU1, iU1);
+        if (by_on) centre(qY, iY);
+        if (bv_on) centre(qV, iV);
+        if (rr_on) centre(qR, iR);
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j) if (ro_on[j]) vO[j] = fmin(RS_RHO, mu * iO[j]);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) lam[i] = 0.0;
+        nfilt = 0;
+        eval_lane(X, U, sR, sO, eP, eN, sp, cp, td, dfc, rR, rO, Up0, Up1, th, fl, prod);
+        double sw[3] = {th, fl, log(prod)};
+        wv::reduce<3, 0>(sw, nullptr);
+        theta = wv::uni(sw[0]); fval = wv::uni(sw[1]); logsum = wv::uni(sw[2]);
+        theta_max = wv::uni(1e4 * fmax(1.0, theta)); theta_min = wv::uni(1e-4 * fmax(1.0, theta));
+        row_grads(sp, cp);
+        rit = 0; slow_run = 0;
+      }
       MPCB_STAMP(t_a);
       // ----- KKT residuals of the scaled problem at the iterate (one pass, fused reductions) ---------------------
       const double a02 = -T * X[3] * sp, a03 = T * cp, a12 = T * X[3] * cp, a13 = T * sp, a23 = T * td * il, b20 = T * X[3] * sec2 * il;
@@ -534,11 +719,11 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         const double Un0 = wv::shfl(U[0], k + 1), Un1 = wv::shfl(U[1], k + 1);
         const double yR = rr_on ? item_y(qR, iR) : 0.0;
         const double yRn = wv::shfl(yR, k + 1);
-        double sum_lam = 0, sum_v = 0, svmax = 0, svmin = 1e300, prim = 0;
+        double sum_lam = 0, sum_v = 0, svmax = 0, svmin = 1e300, prim = 0, edual_el = 0, Vel = 0;
         if (xnode) {
-          if (k < N) {
+          if (RESTO || k < N) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) rX[i] += cst[CS_WQ + i] * (X[i] - cst[CS_XS + i]);
+            for (int i = 0; i < NX; ++i) rX[i] += cWQ(i) * (X[i] - cXS(i));
           }
 #pragma unroll
           for (int i = 0; i < NX; ++i) { rX[i] -= lam[i]; sum_lam += fabs(lam[i]); }
@@ -549,12 +734,12 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           }
         }
         if (hasu) {
-          rU[0] += cst[CS_WR] * U[0]; rU[1] += cst[CS_WR + 1] * U[1];
+          rU[0] += cWR(0) * (U[0] - cUR(0)); rU[1] += cWR(1) * (U[1] - cUR(1));
           if (k > 0 || c.du0_cost) {
-            rU[0] += cst[CS_WDR] * (U[0] - (k ? Up0 : cst[CS_UL]));
-            rU[1] += cst[CS_WDR + 1] * (U[1] - (k ? Up1 : cst[CS_UL + 1]));
+            rU[0] += cWDR(0) * (U[0] - (k ? Up0 : cst[CS_UL]));
+            rU[1] += cWDR(1) * (U[1] - (k ? Up1 : cst[CS_UL + 1]));
           }
-          if (k + 1 < N) { rU[0] -= cst[CS_WDR] * (Un0 - U[0]); rU[1] -= cst[CS_WDR + 1] * (Un1 - U[1]); }
+          if (k + 1 < N) { rU[0] -= cWDR(0) * (Un0 - U[0]); rU[1] -= cWDR(1) * (Un1 - U[1]); }
           rU[0] += b20 * ln[2]; rU[1] += T * ln[3];
           if (k + 1 < N) rU[0] += yRn;                                          // d(row k+1)/dU_k = -1
         }
@@ -573,8 +758,14 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           if (GEN) { rX[2] -= vO[j] * gO2[j]; rX[3] -= vO[j] * gO3[j]; }
           const double p = (sO[j] - qO.L) * vO[j]; svmax = fmax(svmax, p); svmin = fmin(svmin, p); sum_v += vO[j];
           prim = fmax(prim, fabs(rO[j]));
+          if (RESTO && rs) {     // stationarity in p and n (rho + y - vp = 0, rho - y - vn = 0) and their complementarity
+            edual_el = fmax(edual_el, fmax(fabs(RS_RHO + vO[j] - vP[j]), fabs(RS_RHO - vO[j] - vN[j])));
+            const double cp_ = eP[j] * vP[j], cn_ = eN[j] * vN[j];
+            svmax = fmax(svmax, fmax(cp_, cn_)); svmin = fmin(svmin, fmin(cp_, cn_)); sum_v += vP[j] + vN[j];
+            Vel += eP[j] + eN[j];
+          }
         }
-        double dual = 0;
+        double dual = edual_el;
         if (xnode) {
 #pragma unroll
           for (int i = 0; i < NX; ++i) dual = fmax(dual, fabs(rX[i]));
@@ -584,29 +775,125 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
 #pragma unroll
           for (int i = 0; i < NX; ++i) prim = fmax(prim, fabs(dfc[i]));
         }
-        double ss[2] = {sum_lam, sum_v}, mm[4] = {dual, prim, svmax, -svmin};
-        wv::reduce<2, 4>(ss, mm);
+        double ss[3] = {sum_lam, sum_v, Vel}, mm[4] = {dual, prim, svmax, -svmin};
+        wv::reduce<RESTO ? 3 : 2, 4>(ss, mm);
         e_dual = wv::uni(mm[0]); e_prim = wv::uni(mm[1]);
         const double sv_hi = wv::uni(mm[2]), sv_lo = -wv::uni(mm[3]);
-        const double e_sd = fmax(S_MAX, (wv::uni(ss[0]) + wv::uni(ss[1])) / fmax(1.0, n_lam + n_v)) / S_MAX;
-        const double e_sc = fmax(S_MAX, wv::uni(ss[1]) / fmax(1.0, n_v)) / S_MAX;
+        const double n_vr = (RESTO && rs) ? n_v + 2 * n_el : n_v;               // bound multipliers of the running phase
+        const double e_sd = fmax(S_MAX, (wv::uni(ss[0]) + wv::uni(ss[1])) / fmax(1.0, n_lam + n_vr)) / S_MAX;
+        const double e_sc = fmax(S_MAX, wv::uni(ss[1]) / fmax(1.0, n_vr)) / S_MAX;
         const double base = fmax(e_dual / e_sd, e_prim);
-        err0 = fmax(base, (n_v > 0 ? sv_hi : 0.0) / e_sc);                       // complementarity error at mu = 0
-        if (a.trace && b == a.trace_instance && lane == 0) {
+        err0 = fmax(base, (n_vr > 0 ? sv_hi : 0.0) / e_sc);                      // complementarity error at mu = 0
+        if (a.trace && b == a.trace_instance && lane == 0 && iters <= c.max_iter) {
           double* t = a.trace + (size_t)iters * 8;
           t[0] = mu; t[1] = err0; t[2] = theta; t[3] = fval;
         }
-        if (err0 <= c.tol) { status = MPCB_ST_SOLVED; break; }
-        if (iters >= c.max_iter) { status = MPCB_ST_MAXITER; break; }
+        if (!(RESTO && rs)) {
+          if (err0 <= c.tol) { status = MPCB_ST_SOLVED; break; }
+          if (iters >= c.max_iter) { status = MPCB_ST_MAXITER; break; }
+        } else {
+          // ----- restoration phase: has it done its job?  Violation of the ORIGINAL rows and the original barrier function here
+          double t1 = fabs(rR), fm = 0, pl = 1.0, ti = fabs(rR);
+          if (hasu) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { t1 += fabs(dfc[i]); ti = fmax(ti, fabs(dfc[i])); }
+          }
+#pragma unroll
+          for (int j = 0; j < NOBS; ++j) if (ro_on[j]) { const double r0 = rO[j] + (eP[j] - eN[j]); t1 += fabs(r0); ti = fmax(ti, fabs(r0)); pl *= sO[j] - qO.L; }
+          auto dist = [&](const Bnd& q, double s_) { if (q.hasL) pl *= s_ - q.L; if (q.hasU) pl *= q.U - s_; };
+          if (bu0_on) dist(qU0, U[0]);
+          if (bu1_on) dist(qU1, U[1]);
+          if (by_on) dist(qY, X[1]);
+          if (bv_on) dist(qV, X[3]);
+          if (rr_on) dist(qR, sR);
+          if (hasu) {      // kin.py:195-205 with the main phase's constants
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { const double e = X[i] - cst[CS_XS + i]; fm += cst[CS_Q + i] * e * e; }
+            fm += cst[CS_R] * U[0] * U[0] + cst[CS_R + 1] * U[1] * U[1];
+            if (k > 0 || c.du0_cost) {
+              const double d0 = U[0] - (k ? Up0 : cst[CS_UL]), d1 = U[1] - (k ? Up1 : cst[CS_UL + 1]);
+              fm += cst[CS_DR] * d0 * d0 + cst[CS_DR + 1] * d1 * d1;
+            }
+          }
+          double so[3] = {t1, fm, log(pl)}, mo[1] = {ti};
+          wv::reduce<3, 1>(so, mo);
+          const double th1 = wv::uni(so[0]), thinf = wv::uni(mo[0]);
+          bool leave = false;
+          if (rit >= 1 && th1 <= RS_KAPPA * th_entry && th1 <= tmax_main) {
+            const double phi_o = os * wv::uni(so[1]) - mu_main * wv::uni(so[2]);
+            leave = !(th1 >= fm_theta && phi_o >= fm_phi);                          // acceptable to the main filter (= the entry pair)
+          }
+          if (!leave && err0 <= c.tol) {
+            // the restoration problem itself is solved: violated rows -> locally infeasible; a feasible point that the main phase
+            // could not leave (no restoration step was taken) -> the restoration has nothing to offer (IPOPT: Restoration_Failed)
+            if (thinf > c.tol) { status = MPCB_ST_INFEASIBLE; break; }
+            if (rit == 0) { status = MPCB_ST_RESTO_FAILED; break; }
+            leave = true;
+          }
+          if (!leave) {
+            // local-infeasibility certificate: barrier subproblem solved, hard rows satisfied, elastic violation above the gap bound
+            const double V = wv::uni(ss[2]);
+            const double em = fmax(base, fmax(fabs(sv_hi - mu), fabs(sv_lo - mu)) / e_sc);
+            const double gap = (RS_GAP * n_vr * mu + 0.5 * (double)((NX + NU) * N) * sqrt(mu)) / RS_RHO;
+            if (em <= K_EPS * mu && V > gap + 1e-6 && theta <= 0.01 * V) { status = MPCB_ST_INFEASIBLE; break; }
+            if (iters >= c.max_iter) { status = MPCB_ST_MAXITER; break; }
+          } else {
+            // ----- back to the main phase: original cost, mu and filter bounds; lam = 0; bound duals kept unless one exceeds 1000
+            rs = false; osc = os; write_main_cost();
+            double vm = 0;
+            auto vmx = [&](const Bnd& q, const Item& it) { if (q.hasL) vm = fmax(vm, it.vL); if (q.hasU) vm = fmax(vm, it.vU); };
+            if (bu0_on) vmx(qU0, iU0);
+            if (bu1_on) vmx(qU1, iU1);
+            if (by_on) vmx(qY, iY);
+            if (bv_on) vmx(qV, iV);
+            if (rr_on) vmx(qR, iR);
+#pragma unroll
+            for (int j = 0; j < NOBS; ++j) { if (ro_on[j]) vm = fmax(vm, vO[j]); }
+#pragma unroll
+            for (int j = 0; j < NEL; ++j) { eP[j] = 0; eN[j] = 0; vP[j] = 0; vN[j] = 0; }
+            if (wv::uni(wv::max(vm)) > 1000.0) {
+              iU0.vL = iU0.vU = iU1.vL = iU1.vU = iY.vL = iY.vU = iV.vL = iV.vU = iR.vL = iR.vU = 1.0;
+#pragma unroll
+              for (int j = 0; j < NOBS; ++j) vO[j] = 1.0;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) lam[i] = 0.0;
+            mu = mu_main; tau = fmax(TAU_MIN, 1.0 - mu);
+            theta_max = tmax_main; theta_min = tmin_main;
+            if (lane == 0) { filt[0] = fm_theta; filt[1] = fm_phi; }
+            nfilt = 1;
+            wv::sync();
+            double th, fl, prod;
+            eval_lane(X, U, sR, sO, eP, eN, sp, cp, td, dfc, rR, rO, Up0, Up1, th, fl, prod);
+            double sw[3] = {th, fl, log(prod)};
+            wv::reduce<3, 0>(sw, nullptr);
+            theta = wv::uni(sw[0]); fval = wv::uni(sw[1]); logsum = wv::uni(sw[2]);
+            slow_run = 0;
+            continue;
+          }
+        }
         // barrier parameter update (monotone, Fiacco-McCormick): max_i |s_i v_i - mu| from the two extremes
+        const double mu_before = mu;
         for (;;) {
-          const double comp = (n_v > 0) ? fmax(fabs(sv_hi - mu), fabs(sv_lo - mu)) : 0.0;
+          const double comp = (n_vr > 0) ? fmax(fabs(sv_hi - mu), fabs(sv_lo - mu)) : 0.0;
           const double em = fmax(base, comp / e_sc);
           if (em <= K_EPS * mu && mu > mu_floor) {
             mu = wv::uni(fmax(mu_floor, fmin(K_MU * mu, mu * sqrt(mu))));
             tau = wv::uni(fmax(TAU_MIN, 1.0 - mu));
             nfilt = 0;
           } else break;
+        }
+        if (RESTO && rs && mu != mu_before) {      // the proximity weight follows mu: zeta = sqrt(mu); objective value of the new cost
+          write_resto_cost(sqrt(mu), false, X, U);
+          double fl = 0;
+          if (xobj) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { const double e = X[i] - cXS(i); fl += cQQ(i) * e * e; }
+          }
+          if (hasu) { const double e0 = U[0] - cUR(0), e1 = U[1] - cUR(1); fl += cRR(0) * e0 * e0 + cRR(1) * e1 * e1; }
+#pragma unroll
+          for (int j = 0; j < NOBS; ++j) if (ro_on[j]) fl += RS_RHO * (eP[j] + eN[j]);
+          fval = wv::uni(wv::sum(fl));
         }
       }
 
@@ -615,16 +902,16 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       double hxp = 0, hxv = 0, hyp = 0, hyv = 0;      // GEN only
       {
         double g[NW] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (xcost) {
-          hxx += cst[CS_WQ]; hyy += cst[CS_WQ + 1]; hpp += cst[CS_WQ + 2]; hvv += cst[CS_WQ + 3];
+        if (xq) {
+          hxx += cWQ(0); hyy += cWQ(1); hpp += cWQ(2); hvv += cWQ(3);
 #pragma unroll
-          for (int i = 0; i < NX; ++i) g[i] += cst[CS_WQ + i] * (X[i] - cst[CS_XS + i]);
+          for (int i = 0; i < NX; ++i) g[i] += cWQ(i) * (X[i] - cXS(i));
         }
         if (hasu) {
-          hdd += cst[CS_WR]; haa += cst[CS_WR + 1];
-          g[6] += cst[CS_WR] * U[0]; g[7] += cst[CS_WR + 1] * U[1];
+          hdd += cWR(0); haa += cWR(1);
+          g[6] += cWR(0) * (U[0] - cUR(0)); g[7] += cWR(1) * (U[1] - cUR(1));
           if (k > 0 || c.du0_cost) {
-            const double w0 = cst[CS_WDR], w1 = cst[CS_WDR + 1];
+            const double w0 = cWDR(0), w1 = cWDR(1);
             const double d0 = U[0] - (k ? Up0 : cst[CS_UL]), d1 = U[1] - (k ? Up1 : cst[CS_UL + 1]);
             hdd += w0; h44 += w0; h46 -= w0; haa += w1; h55 += w1; h57 -= w1;
             g[6] += w0 * d0; g[4] -= w0 * d0; g[7] += w1 * d1; g[5] -= w1 * d1;
@@ -644,7 +931,13 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         if (rr_on) { item_sig_gb(iR, rR, mu, sig, gb); hdd += sig; h44 += sig; h46 -= sig; g[6] -= gb; g[4] += gb; }
 #pragma unroll
         for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
-          sig = vO[j] * iO[j]; gb = mu * iO[j] - sig * rO[j];
+          sig = vO[j] * iO[j]; gb = mu * iO[j];
+          if (RESTO && rs) {   // elastic row: Sigma_e = kappa Sigma_s and the residual r~ (oracle: build_stage_grad)
+            const double isp = eP[j] / vP[j], isn = eN[j] / vN[j];              // 1 / Sigma_p, 1 / Sigma_n
+            const double kap = 1.0 / (1.0 + sig * isp + sig * isn);
+            const double rt = rO[j] + (RS_RHO + gb - mu / eP[j]) * isp + (gb - RS_RHO + mu / eN[j]) * isn;
+            sig *= kap; gb -= sig * rt;
+          } else gb -= sig * rO[j];
           if (!GEN) {
             hxx += sig * gO0[j] * gO0[j] - vO[j] * 2 * ix2[j];
             hxy += sig * gO0[j] * gO1[j];
@@ -856,11 +1149,23 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       }
       // slack steps of the general rows
       const double dsR = rr_on ? (dU[0] - dUp0) + rR : 0.0;
-      double dsO[NOB];
+      double dsO[NOB], dP[NEL], dN[NEL], dvP[NEL], dvN[NEL];
+#pragma unroll
+      for (int j = 0; j < NEL; ++j) { dP[j] = 0; dN[j] = 0; dvP[j] = 0; dvN[j] = 0; }
 #pragma unroll
       for (int j = 0; j < NOBS; ++j) {
         dsO[j] = ro_on[j] ? gO0[j] * dX[0] + gO1[j] * dX[1] + rO[j] : 0.0;
         if (GEN && ro_on[j]) dsO[j] += gO2[j] * dX[2] + gO3[j] * dX[3];
+        if (RESTO && rs && ro_on[j]) {        // elastic row (oracle: riccati_vector)
+          const double sig = vO[j] * iO[j], bs = mu * iO[j];
+          const double sp_ = vP[j] / eP[j], sn_ = vN[j] / eN[j], kap = 1.0 / (1.0 + sig / sp_ + sig / sn_);
+          const double cp_ = (RS_RHO + bs - mu / eP[j]) / sp_, cn_ = (bs - RS_RHO + mu / eN[j]) / sn_;
+          dsO[j] = kap * (dsO[j] + cp_ + cn_);
+          dP[j] = sig * dsO[j] / sp_ - cp_;
+          dN[j] = -sig * dsO[j] / sn_ + cn_;
+          dvP[j] = mu / eP[j] - vP[j] - sp_ * dP[j];
+          dvN[j] = mu / eN[j] - vN[j] - sn_ * dN[j];
+        }
       }
 
       // ----- fraction to the boundary (as the largest step ratios) and d(barrier function) along the step --------
@@ -881,16 +1186,20 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
           const double dv = mu * iO[j] - vO[j] - vO[j] * iO[j] * dsO[j];
           rpr = fmax(rpr, -dsO[j] * iO[j]); rdu = fmax(rdu, -dv * wv::rcp(vO[j])); d -= mu * dsO[j] * iO[j];
+          if (RESTO && rs) {
+            rpr = fmax(rpr, fmax(-dP[j] / eP[j], -dN[j] / eN[j])); rdu = fmax(rdu, fmax(-dvP[j] / vP[j], -dvN[j] / vN[j]));
+            d += (RS_RHO - mu / eP[j]) * dP[j] + (RS_RHO - mu / eN[j]) * dN[j];
+          }
         }
-        if (xcost) {
+        if (xq) {
 #pragma unroll
-          for (int i = 0; i < NX; ++i) d += cst[CS_WQ + i] * (X[i] - cst[CS_XS + i]) * dX[i];
+          for (int i = 0; i < NX; ++i) d += cWQ(i) * (X[i] - cXS(i)) * dX[i];
         }
         if (hasu) {
-          d += cst[CS_WR] * U[0] * dU[0] + cst[CS_WR + 1] * U[1] * dU[1];
+          d += cWR(0) * (U[0] - cUR(0)) * dU[0] + cWR(1) * (U[1] - cUR(1)) * dU[1];
           if (k > 0 || c.du0_cost) {
-            d += cst[CS_WDR] * (U[0] - (k ? Up0 : cst[CS_UL])) * (dU[0] - (k ? dUp0 : 0.0));
-            d += cst[CS_WDR + 1] * (U[1] - (k ? Up1 : cst[CS_UL + 1])) * (dU[1] - (k ? dUp1 : 0.0));
+            d += cWDR(0) * (U[0] - (k ? Up0 : cst[CS_UL])) * (dU[0] - (k ? dUp0 : 0.0));
+            d += cWDR(1) * (U[1] - (k ? Up1 : cst[CS_UL + 1])) * (dU[1] - (k ? dUp1 : 0.0));
           }
         }
         double ss[1] = {d}, mm[2] = {rpr, rdu};
@@ -900,7 +1209,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         a_pr = wv::uni((r1 > tau) ? tau / r1 : 1.0);          // min(1, tau / max ratio)
         a_du = wv::uni((r2 > tau) ? tau / r2 : 1.0);
       }
-      const double phi0 = wv::uni(os * fval - mu * logsum), th0 = theta;
+      const double phi0 = wv::uni(osc * fval - mu * logsum), th0 = theta;
       double a_min;
       if (dphi < 0) {
         a_min = fmin(G_THETA, G_PHI * th0 / (-dphi));
@@ -911,7 +1220,9 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       MPCB_STAMP(t_d);
       // ----- filter line search: trial evaluations are lane-parallel ----------------------------------------------
       double alpha = a_pr; bool accepted = false, armijo_type = false;
-      double Xt[NX], Ut[NU], dft[NX], sRt, rRt, sOt[NOB], rOt[NOB], upt0, upt1, st_, ct_, tt_, et_, tht = 0, ft = 0, lst = 0;
+      double Xt[NX], Ut[NU], dft[NX], sRt, rRt, sOt[NOB], rOt[NOB], pt[NEL], nt[NEL], upt0, upt1, st_, ct_, tt_, et_, tht = 0, ft = 0, lst = 0;
+#pragma unroll
+      for (int j = 0; j < NEL; ++j) { pt[j] = 0; nt[j] = 0; }
 #pragma clang loop unroll(disable)
       for (;;) {
 #pragma unroll
@@ -920,13 +1231,17 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         sRt = sR + alpha * dsR;
 #pragma unroll
         for (int j = 0; j < NOBS; ++j) sOt[j] = sO[j] + alpha * dsO[j];
+        if (RESTO && rs) {
+#pragma unroll
+          for (int j = 0; j < NOBS; ++j) { pt[j] = eP[j] + alpha * dP[j]; nt[j] = eN[j] + alpha * dN[j]; }
+        }
         trig(Xt[2], Ut[0], st_, ct_, tt_, et_);
         double th, fl, prod;
-        const bool okl = eval_lane(Xt, Ut, sRt, sOt, st_, ct_, tt_, dft, rRt, rOt, upt0, upt1, th, fl, prod);
+        const bool okl = eval_lane(Xt, Ut, sRt, sOt, pt, nt, st_, ct_, tt_, dft, rRt, rOt, upt0, upt1, th, fl, prod);
         double sv[4] = {th, fl, okl ? log(prod) : 0.0, okl ? 0.0 : 1.0};
         wv::reduce<4, 0>(sv, nullptr);
         tht = wv::uni(sv[0]); ft = wv::uni(sv[1]); lst = wv::uni(sv[2]);
-        const double phit = os * ft - mu * lst;
+        const double phit = osc * ft - mu * lst;
         const bool ok = (wv::uni(sv[3]) == 0.0) && isfinite(tht) && isfinite(phit);
         if (ok && tht <= theta_max) {
           bool fok = true;
@@ -954,7 +1269,20 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         t[4] = (double)(t_b - t_a); t[5] = (double)(t_c - t_b); t[6] = (double)(t_d - t_c); t[7] = (double)(t_e - t_d);
 #endif
       }
-      if (!accepted) { status = MPCB_ST_LINESEARCH; break; }
+      // hand-over of an instance that needs the restoration phase from the first pass to the restoration pass
+      auto hand_over = [&](int it_done) {
+        status = MPCB_ST_NEEDS_RESTO;
+        if (lane == 0 && a.work) {
+          double* wk = a.work + (size_t)b * WK_SIZE;
+          wk[WK_MU] = mu; wk[WK_THMAX] = theta_max; wk[WK_THMIN] = theta_min; wk[WK_ITERS] = (double)it_done; wk[WK_DW] = dw_last;
+        }
+      };
+      if (!accepted) {
+        if (RESTO && rs) { status = MPCB_ST_RESTO_FAILED; break; }                    // the restoration's own line search failed
+        if (!c.restoration) { status = MPCB_ST_LINESEARCH; break; }
+        if (!RESTO) { hand_over(iters); break; }                                      // where IPOPT enters restoration
+        enter = true; continue;
+      }
       if (!armijo_type) {
         if (nfilt < FILTER_MAX) {
           if (lane == 0) { filt[2 * nfilt] = (1 - G_THETA) * th0; filt[2 * nfilt + 1] = phi0 - G_PHI * th0; }
@@ -982,6 +1310,12 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         vO[j] += a_du * dv;
         iO[j] = wv::rcp(sOt[j] - qO.L);
         vO[j] = fmax(fmin(vO[j], K_SIGMA * mu * iO[j]), mu * iO[j] / K_SIGMA);
+        if (RESTO && rs) {
+          eP[j] = pt[j]; eN[j] = nt[j];
+          vP[j] += a_du * dvP[j]; vN[j] += a_du * dvN[j];
+          vP[j] = fmax(fmin(vP[j], K_SIGMA * mu / eP[j]), mu / (K_SIGMA * eP[j]));
+          vN[j] = fmax(fmin(vN[j], K_SIGMA * mu / eN[j]), mu / (K_SIGMA * eN[j]));
+        }
       }
       if (xnode) {
 #pragma unroll
@@ -997,14 +1331,33 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       row_grads(sp, cp);
       theta = tht; fval = ft; logsum = lst;
       if (!isfinite(theta) || !isfinite(fval)) { status = MPCB_ST_NUMERIC; break; }
+      ++iters;
+      if (RESTO && rs) ++rit;
+      else if (c.restoration) {
+        // early entry into restoration: TRIG_K accepted steps in a row shorter than TRIG_ALPHA that together reduced theta by less
+        // than the factor TRIG_THETA (a slack pinned at its bound with the row still violated: the pattern of an infeasible
+        // instance; IPOPT itself waits for the line search to fail, dozens of such steps later)
+        if (alpha < TRIG_ALPHA && theta > 1e-6) { if (slow_run == 0) slow_theta0 = th0; ++slow_run; } else slow_run = 0;
+        if (slow_run >= TRIG_K && theta > TRIG_THETA * slow_theta0) {
+          slow_run = 0;
+          if (!RESTO) { hand_over(iters); break; }
+          enter = true;
+        }
+      }
     }
   } else {
     trig(X[2], U[0], sp, cp, td, sec2);
     double th, fl, prod;
-    eval_lane(X, U, sR, sO, sp, cp, td, dfc, rR, rO, Up0, Up1, th, fl, prod);
+    eval_lane(X, U, sR, sO, eP, eN, sp, cp, td, dfc, rR, rO, Up0, Up1, th, fl, prod);
     fval = wv::sum(fl);
   }
 
+  if (RESTO && rs) {    // ended inside the restoration phase: report the objective of the original problem (kin.py:195-205)
+    rs = false; osc = os; write_main_cost();
+    double th, fl, prod;
+    eval_lane(X, U, sR, sO, eP, eN, sp, cp, td, dfc, rR, rO, Up0, Up1, th, fl, prod);
+    fval = wv::sum(fl);
+  }
   // ----- outputs (reference ordering), staged through LDS for coalesced stores ----------------------------------
   // `ko` = k behind an optimisation barrier: the LDS addresses of the z staging are re-formed here instead of being kept
   // live (and spilled) from the identical expressions at kernel start — hipcc 7.2 mis-reloaded such a spilled address in the

@@ -17,15 +17,20 @@
 //       barrier method, monotone mu, fraction-to-boundary rule, filter line search, inertia correction,
 //       gradient-based objective scaling, bound push / bound relaxation) with the option values the reference
 //       passes (kin.py:252-253: max_iter 100, acceptable_tol 1e-8) and IPOPT's documented defaults otherwise.
-// Results are pinned instead by (a) an independent numpy KKT certificate (oracle/kkt_check.py) and (b) an
-// independent dense numpy interior-point solver (oracle/dense_ipm.py) on the reference's flat z / g ordering.
+// Results are pinned instead by an independent numpy KKT certificate (oracle/kkt_check.py: the NLP written a second time
+// in the reference's flat z / g ordering, complex-step derivatives) and by the committed golden vectors.
 //
 // Deliberate differences from IPOPT (none changes the KKT point that is reached in a given basin):
 //   - X_0 is eliminated (it is pinned by the rows X_0 - P[0:nx] = 0, kin.py:191); rows that only involve X_0
 //     are constants and are reported with zero multipliers.
 //   - the KKT system is solved by a Riccati recursion over the stages (state augmented with the previous
 //     control because of the (U_i - U_{i-1}) cost and rate rows, kin.py:201-204,216) instead of MUMPS.
-//   - no restoration phase: a failed line search ends with MPCB_ST_LINESEARCH.
+//   - restoration phase (cfg.restoration = 1): IPOPT's idea — minimise the l1 norm of the constraint violation plus a
+//     proximity term with the same interior-point method, return to the main problem as soon as a point acceptable to the
+//     (augmented) filter with 10 % less violation is found — in a form that keeps the stage structure: the shooting rows
+//     stay hard (a Riccati sweep always satisfies their linearisation), the general inequality rows (rate, obstacle)
+//     become elastic  c(w) - s - p + n = 0, p, n >= 0  with cost rho (p + n).  See Solver::restoration().
+//     cfg.restoration = 0: a failed line search ends with MPCB_ST_LINESEARCH.
 //   - multipliers of the slack equalities are eliminated (y_d = v_L - v_U); no constraint-row scaling
 //     (every row gradient of this NLP is < max_gradient at sane scenes).
 //
@@ -232,6 +237,9 @@ struct Ineq {
   // discrete-CBF row, which also carries its own 4x4 second derivative hc
   int i0 = -1, i1 = -1, i2 = -1, i3 = -1; double g0 = 0, g1 = 0, g2 = 0, g3 = 0;
   double hc[4][4] = {{0}};
+  // restoration phase only: elastic variables of the row  c(w) - s - p + n = 0  and their duals / steps
+  bool el = false;
+  double p = 0, n = 0, vp = 0, vn = 0, dp = 0, dn = 0, dvp = 0, dvn = 0;
   int idx(int a) const { return a == 0 ? i0 : a == 1 ? i1 : a == 2 ? i2 : i3; }
   double gv(int a) const { return a == 0 ? g0 : a == 1 ? g1 : a == 2 ? g2 : g3; }
   double y() const { return (hasL ? vL : 0.0) - (hasU ? vU : 0.0); }
@@ -244,6 +252,12 @@ struct Opt {   // line-search / barrier constants of IPOPT (Waechter-Biegler 200
   double gamma_theta = 1e-5, gamma_phi = 1e-8, delta = 1.0, s_theta = 1.1, s_phi = 2.3, eta_phi = 1e-8;
   double gamma_alpha = 0.05, kappa_sigma = 1e10, s_max = 100.0;
   double dw_first = 1e-4, dw_min = 1e-20, dw_max = 1e40, kw_minus = 1.0 / 3.0, kw_plus = 8.0, kw_plus_first = 100.0;
+  // restoration phase
+  double resto_rho = 1000.0;       // IPOPT resto_penalty_parameter
+  double resto_kappa = 0.5;        // leave restoration when the original violation is <= resto_kappa * violation at entry (IPOPT: 0.9)
+  double gap_safety = 10.0;        // safety factor on the barrier duality gap n_v * mu in the local-infeasibility certificate
+  int trig_k = 5; double trig_alpha = 0.05, trig_theta = 0.8;   // early entry: trig_k consecutive accepted steps < trig_alpha with
+                                                                //   theta reduced by less than the factor trig_theta over them
 };
 
 struct Solver {
@@ -258,6 +272,15 @@ struct Solver {
   double X[NODES][NXM], U[NODES][NU], lam[NODES][NXM];
   Ineq bU[NODES][NU], bX[NODES][NXM], rR[NODES][NU], rO[NODES][NOBM];
   double os = 1.0, mu = 0.1, tau = 0.99;
+
+  // the objective of the current phase:  sum_k sum_i Qc[k][i] (X_k,i - Xr[k][i])^2 + Rc[k][i] (U_k,i - Ur[k][i])^2 + DRc[i] (dU)^2,
+  // scaled by osc.  Main phase: Q, xs, R, 0, DR of the reference (kin.py:168-205), osc = os.  Restoration phase: the proximity
+  // term zeta/2 ||D_R (w - w_R)||^2 of IPOPT's restoration problem, osc = 1, plus rho (p + n) over the elastic rows.
+  double Qc[NODES][NXM], Xr[NODES][NXM], Rc[NODES][NU], Ur[NODES][NU], DRc[NU], osc = 1.0;
+  bool resto = false;
+  double rho = 1000.0;                 // IPOPT resto_penalty_parameter
+  double XR[NODES][NXM], UR[NODES][NU];   // reference point of the proximity term (the iterate at which restoration started)
+  int n_resto_calls = 0, n_resto_iters = 0;
 
   // evaluation at the iterate
   ModelEval me[NODES];
@@ -284,6 +307,12 @@ struct Solver {
     if (std::getenv("MPCO_THMU")) o.theta_mu = std::atof(std::getenv("MPCO_THMU"));
     if (std::getenv("MPCO_KEPS")) o.kappa_eps = std::atof(std::getenv("MPCO_KEPS"));
     if (std::getenv("MPCO_TAUMIN")) o.tau_min = std::atof(std::getenv("MPCO_TAUMIN"));
+    if (std::getenv("MPCO_KRESTO")) o.resto_kappa = std::atof(std::getenv("MPCO_KRESTO"));
+    if (std::getenv("MPCO_GAP")) o.gap_safety = std::atof(std::getenv("MPCO_GAP"));
+    if (std::getenv("MPCO_TRIG_K")) o.trig_k = std::atoi(std::getenv("MPCO_TRIG_K"));
+    if (std::getenv("MPCO_TRIG_A")) o.trig_alpha = std::atof(std::getenv("MPCO_TRIG_A"));
+    if (std::getenv("MPCO_TRIG_TH")) o.trig_theta = std::atof(std::getenv("MPCO_TRIG_TH"));
+    rho = o.resto_rho;
     N = c.N; nx = nx_of(c); na = nx + NU; nw = na + NU; nobs = c.n_obs;
   }
 
@@ -395,6 +424,7 @@ struct Solver {
       }
     }
 
+    set_main_cost();
     // feasibility of the pinned node 0 (rows that IPOPT could never satisfy)
     for (int i = 0; i < nx; ++i)
       if (x0[i] < c.x_lo[i] - 1e-8 || x0[i] > c.x_hi[i] + 1e-8) { status = MPCB_ST_INFEASIBLE_X0; return false; }
@@ -431,19 +461,51 @@ struct Solver {
       }
     }
     mu = c.mu_init; tau = std::max(o.tau_min, 1.0 - mu);
+    set_main_cost();
     return true;
   }
 
   // ----- evaluation at the current iterate ------------------------------------------------------------------
-  double objective(const double Xa[][NXM], const double Ua[][NU]) const {   // unscaled, kin.py:195-205
-    double f = 0;
-    for (int k = 0; k < N; ++k) {
-      for (int i = 0; i < nx; ++i) { double e = Xa[k][i] - xs[i]; f += c.Q[i] * e * e; }
+  void set_main_cost() {                 // kin.py:168-205 / dyn.py:189-225
+    for (int k = 0; k <= N; ++k) {
+      for (int i = 0; i < NXM; ++i) { Qc[k][i] = (k < N && i < nx) ? c.Q[i] : 0.0; Xr[k][i] = (i < nx) ? xs[i] : 0.0; }   // no terminal cost
+      for (int i = 0; i < NU; ++i) { Rc[k][i] = (k < N) ? c.R[i] : 0.0; Ur[k][i] = 0.0; }
+    }
+    for (int i = 0; i < NU; ++i) DRc[i] = c.DR[i];
+    osc = os;
+  }
+  void set_resto_cost(double zeta) {     // zeta/2 * sum D^2 (w - w_R)^2,  D = 1 / max(1, |w_R|)
+    for (int k = 0; k <= N; ++k) {
+      for (int i = 0; i < NXM; ++i) {
+        const double d = 1.0 / std::max(1.0, std::fabs(XR[k][i]));
+        Qc[k][i] = (k >= 1 && i < nx) ? 0.5 * zeta * d * d : 0.0; Xr[k][i] = XR[k][i];
+      }
       for (int i = 0; i < NU; ++i) {
-        f += c.R[i] * Ua[k][i] * Ua[k][i];
-        if (k > 0 || c.du0_cost) { double d = Ua[k][i] - (k ? Ua[k - 1][i] : c.u_last[i]); f += c.DR[i] * d * d; }
+        const double d = 1.0 / std::max(1.0, std::fabs(UR[k][i]));
+        Rc[k][i] = (k < N) ? 0.5 * zeta * d * d : 0.0; Ur[k][i] = UR[k][i];
       }
     }
+    for (int i = 0; i < NU; ++i) DRc[i] = 0.0;
+    osc = 1.0;
+  }
+  bool du_cost(int k) const { return k > 0 || c.du0_cost; }
+
+  // objective of the current phase without the elastic part (unscaled)
+  double objective(const double Xa[][NXM], const double Ua[][NU]) const {
+    double f = 0;
+    for (int k = 0; k <= N; ++k) {
+      for (int i = 0; i < nx; ++i) { double e = Xa[k][i] - Xr[k][i]; f += Qc[k][i] * e * e; }
+      if (k < N) for (int i = 0; i < NU; ++i) {
+        double e = Ua[k][i] - Ur[k][i];
+        f += Rc[k][i] * e * e;
+        if (du_cost(k)) { double d = Ua[k][i] - (k ? Ua[k - 1][i] : c.u_last[i]); f += DRc[i] * d * d; }
+      }
+    }
+    return f;
+  }
+  double elastic_cost() const {
+    double f = 0;
+    if (resto) for (int k = 0; k <= N; ++k) const_cast<Solver*>(this)->each_item(k, [&](Ineq& it) { if (it.el) f += rho * (it.p + it.n); });
     return f;
   }
 
@@ -456,21 +518,22 @@ struct Solver {
     for (int k = 0; k <= N; ++k) {
       for (int i = 0; i < NU; ++i) if (bU[k][i].on) { bU[k][i].s = U[k][i]; bU[k][i].r = 0; }
       for (int i = 0; i < nx; ++i) if (bX[k][i].on) { bX[k][i].s = X[k][i]; bX[k][i].r = 0; }
-      for (int i = 0; i < NU; ++i) if (rR[k][i].on) { rR[k][i].r = (U[k][i] - U[k - 1][i]) - rR[k][i].s; theta += std::fabs(rR[k][i].r); }
+      for (int i = 0; i < NU; ++i) if (rR[k][i].on) { Ineq& it = rR[k][i]; it.r = (U[k][i] - U[k - 1][i]) - it.s - (it.el ? it.p - it.n : 0.0); theta += std::fabs(it.r); }
       for (int j = 0; j < nobs; ++j) if (rO[k][j].on) {
         Ineq& it = rO[k][j]; const ObsP& q = obs[k][j];
-        it.r = rowval(k, j, X[k]) - it.s; theta += std::fabs(it.r);
+        it.r = rowval(k, j, X[k]) - it.s - (it.el ? it.p - it.n : 0.0); theta += std::fabs(it.r);
         (void)q; row_derivs(k, j, X[k], it);
       }
     }
-    fval = objective(X, U);
+    fval = objective(X, U) + elastic_cost();
   }
 
   double barrier_phi(double f_unscaled, double mu_) {
-    double phi = os * f_unscaled;
+    double phi = osc * f_unscaled;
     for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) {
       if (it.hasL) phi -= mu_ * std::log(it.s - it.L);
       if (it.hasU) phi -= mu_ * std::log(it.U - it.s);
+      if (it.el) phi -= mu_ * (std::log(it.p) + std::log(it.n));
     });
     return phi;
   }
@@ -483,15 +546,15 @@ struct Solver {
     for (int k = 0; k <= N; ++k) {
       double rX[NXM] = {0}, rU[NU] = {0};
       if (k >= 1) {
-        if (k < N) for (int i = 0; i < nx; ++i) rX[i] += os * 2 * c.Q[i] * (X[k][i] - xs[i]);
+        for (int i = 0; i < nx; ++i) rX[i] += osc * 2 * Qc[k][i] * (X[k][i] - Xr[k][i]);
         for (int i = 0; i < nx; ++i) { rX[i] -= lam[k][i]; sum_lam += std::fabs(lam[k][i]); ++n_lam; }
         if (k < N) for (int i = 0; i < nx; ++i) for (int a = 0; a < nx; ++a) rX[i] += me[k].A[a][i] * lam[k + 1][a];
       }
       if (k < N) {
         for (int i = 0; i < NU; ++i) {
-          rU[i] += os * 2 * c.R[i] * U[k][i];
-          if (k > 0 || c.du0_cost) rU[i] += os * 2 * c.DR[i] * (U[k][i] - (k ? U[k - 1][i] : c.u_last[i]));
-          if (k + 1 < N) rU[i] -= os * 2 * c.DR[i] * (U[k + 1][i] - U[k][i]);
+          rU[i] += osc * 2 * Rc[k][i] * (U[k][i] - Ur[k][i]);
+          if (du_cost(k)) rU[i] += osc * 2 * DRc[i] * (U[k][i] - (k ? U[k - 1][i] : c.u_last[i]));
+          if (k + 1 < N) rU[i] -= osc * 2 * DRc[i] * (U[k + 1][i] - U[k][i]);
           for (int a = 0; a < nx; ++a) rU[i] += me[k].B[a][i] * lam[k + 1][a];
           if (k + 1 < N && rR[k + 1][i].on) rU[i] += rR[k + 1][i].y();      // d(row k+1)/dU_k = -1
         }
@@ -506,6 +569,11 @@ struct Solver {
         for (int a = 0; a < 4; ++a) add(it.idx(a), it.gv(a));
         if (it.hasL) { e.comp = std::max(e.comp, std::fabs((it.s - it.L) * it.vL - mu_)); sum_v += it.vL; ++n_v; }
         if (it.hasU) { e.comp = std::max(e.comp, std::fabs((it.U - it.s) * it.vU - mu_)); sum_v += it.vU; ++n_v; }
+        if (it.el) {   // stationarity in p and n: rho + y - vp = 0, rho - y - vn = 0
+          e.dual = std::max(e.dual, std::max(std::fabs(rho + y - it.vp), std::fabs(rho - y - it.vn)));
+          e.comp = std::max(e.comp, std::max(std::fabs(it.p * it.vp - mu_), std::fabs(it.n * it.vn - mu_)));
+          sum_v += it.vp + it.vn; n_v += 2;
+        }
         e.prim = std::max(e.prim, std::fabs(it.r));
       });
       if (k >= 1) for (int i = 0; i < nx; ++i) e.dual = std::max(e.dual, std::fabs(rX[i]));
@@ -514,7 +582,7 @@ struct Solver {
     }
     e.sd = std::max(o.s_max, (sum_lam + sum_v) / std::max(1, n_lam + n_v)) / o.s_max;
     e.sc = std::max(o.s_max, sum_v / std::max(1, n_v)) / o.s_max;
-    if (dual_unscaled) *dual_unscaled = e.dual / os;
+    if (dual_unscaled) *dual_unscaled = e.dual / osc;
     return e;
   }
   double Emu(const Err& e) const { return std::max(e.dual / e.sd, std::max(e.prim, e.comp / e.sc)); }
@@ -526,12 +594,12 @@ struct Solver {
   void build_stage_matrix(int k, double dw) {
     double (*Hk)[NWM] = H[k];
     for (int i = 0; i < NWM; ++i) for (int j = 0; j < NWM; ++j) Hk[i][j] = 0;
-    if (k >= 1 && k < N) for (int i = 0; i < nx; ++i) Hk[i][i] += os * 2 * c.Q[i];
+    if (k >= 1) for (int i = 0; i < nx; ++i) Hk[i][i] += osc * 2 * Qc[k][i];
     if (k < N) {
       for (int i = 0; i < NU; ++i) {
         int iu = na + i, ip = nx + i;
-        Hk[iu][iu] += os * 2 * c.R[i];
-        if (k > 0 || c.du0_cost) { double w2 = os * 2 * c.DR[i]; Hk[iu][iu] += w2; Hk[ip][ip] += w2; Hk[iu][ip] -= w2; Hk[ip][iu] -= w2; }
+        Hk[iu][iu] += osc * 2 * Rc[k][i];
+        if (du_cost(k)) { double w2 = osc * 2 * DRc[i]; Hk[iu][iu] += w2; Hk[ip][ip] += w2; Hk[iu][ip] -= w2; Hk[ip][iu] -= w2; }
       }
       double Hc[NVM][NVM];
       ModelEval tmp;
@@ -543,6 +611,7 @@ struct Solver {
       double sig = 0;
       if (it.hasL) sig += it.vL / (it.s - it.L);
       if (it.hasU) sig += it.vU / (it.U - it.s);
+      if (it.el) sig = sig / (1.0 + sig * it.p / it.vp + sig * it.n / it.vn);     // series combination with Sigma_p, Sigma_n
       for (int a = 0; a < 4; ++a) if (it.idx(a) >= 0)
         for (int b = 0; b < 4; ++b) if (it.idx(b) >= 0) Hk[it.idx(a)][it.idx(b)] += sig * it.gv(a) * it.gv(b);
     });
@@ -559,12 +628,12 @@ struct Solver {
   void build_stage_grad(int k) {
     double* gk = g[k];
     for (int i = 0; i < NWM; ++i) gk[i] = 0;
-    if (k >= 1 && k < N) for (int i = 0; i < nx; ++i) gk[i] += os * 2 * c.Q[i] * (X[k][i] - xs[i]);
+    if (k >= 1) for (int i = 0; i < nx; ++i) gk[i] += osc * 2 * Qc[k][i] * (X[k][i] - Xr[k][i]);
     if (k < N) for (int i = 0; i < NU; ++i) {
       int iu = na + i, ip = nx + i;
-      gk[iu] += os * 2 * c.R[i] * U[k][i];
-      if (k > 0 || c.du0_cost) {
-        double d = U[k][i] - (k ? U[k - 1][i] : c.u_last[i]), w2 = os * 2 * c.DR[i];
+      gk[iu] += osc * 2 * Rc[k][i] * (U[k][i] - Ur[k][i]);
+      if (du_cost(k)) {
+        double d = U[k][i] - (k ? U[k - 1][i] : c.u_last[i]), w2 = osc * 2 * DRc[i];
         gk[iu] += w2 * d; gk[ip] -= w2 * d;
       }
     }
@@ -572,7 +641,12 @@ struct Solver {
       double sig = 0, gb = 0;
       if (it.hasL) { sig += it.vL / (it.s - it.L); gb += it.tL / (it.s - it.L); }
       if (it.hasU) { sig += it.vU / (it.U - it.s); gb -= it.tU / (it.U - it.s); }
-      gb -= sig * it.r;
+      if (!it.el) gb -= sig * it.r;
+      else {         // elastic row: Sigma_e = kappa Sigma_s, residual r~ (see restoration())
+        const double sp = it.vp / it.p, sn = it.vn / it.n, kap = 1.0 / (1.0 + sig / sp + sig / sn);
+        const double rt = it.r + (rho + gb - it.tL / it.p) / sp + (gb - rho + it.tL / it.n) / sn;
+        gb -= sig * kap * rt;
+      }
       for (int a = 0; a < 4; ++a) if (it.idx(a) >= 0) gk[it.idx(a)] -= gb * it.gv(a);
     });
   }
@@ -652,6 +726,18 @@ struct Solver {
         return dU[k][idx - na];
       };
       it.ds = it.g0 * comp(it.i0) + it.g1 * comp(it.i1) + it.g2 * comp(it.i2) + it.g3 * comp(it.i3) + it.r;
+      if (it.el) {
+        double sig = 0, bs = 0;
+        if (it.hasL) { sig += it.vL / (it.s - it.L); bs += it.tL / (it.s - it.L); }
+        if (it.hasU) { sig += it.vU / (it.U - it.s); bs -= it.tU / (it.U - it.s); }
+        const double sp = it.vp / it.p, sn = it.vn / it.n, kap = 1.0 / (1.0 + sig / sp + sig / sn);
+        const double cp = (rho + bs - it.tL / it.p) / sp, cn = (bs - rho + it.tL / it.n) / sn;
+        it.ds = kap * (it.ds + cp + cn);
+        it.dp = sig * it.ds / sp - cp;
+        it.dn = -sig * it.ds / sn + cn;
+        it.dvp = it.tL / it.p - it.vp - sp * it.dp;
+        it.dvn = it.tL / it.n - it.vn - sn * it.dn;
+      }
       if (it.hasL) { double d = it.s - it.L; it.dvL = it.tL / d - it.vL - it.vL / d * it.ds; }
       if (it.hasU) { double d = it.U - it.s; it.dvU = it.tU / d - it.vU + it.vU / d * it.ds; }
     });
@@ -690,7 +776,7 @@ struct Solver {
       for (int i = 0; i < nx; ++i) t.theta += std::fabs(Xt[k][i] + c.T * f[i] - Xt[k + 1][i]);
     }
     t.f = objective(Xt, Ut);
-    double phi = os * t.f;
+    double phi = osc * t.f;
     for (int k = 0; k <= N; ++k) {
       auto bar = [&](const Ineq& it, double s) {
         if (it.hasL) { double d = s - it.L; if (!(d > 0)) t.ok = false; else phi -= mu_ * std::log(d); }
@@ -698,13 +784,21 @@ struct Solver {
       };
       if (k < N) for (int i = 0; i < NU; ++i) if (bU[k][i].on) bar(bU[k][i], Ut[k][i]);
       if (k >= 1) for (int i = 0; i < nx; ++i) if (bX[k][i].on) bar(bX[k][i], Xt[k][i]);
+      auto elastic = [&](const Ineq& it) -> double {      // p - n of the trial point, barrier and cost terms added to phi
+        if (!it.el) return 0.0;
+        const double pt = it.p + alpha * it.dp, nt = it.n + alpha * it.dn;
+        if (!(pt > 0) || !(nt > 0)) { t.ok = false; return 0.0; }
+        phi += rho * (pt + nt) - mu_ * (std::log(pt) + std::log(nt));
+        t.f += rho * (pt + nt);
+        return pt - nt;
+      };
       if (k >= 1 && k < N) for (int i = 0; i < NU; ++i) if (rR[k][i].on) {
         double s = rR[k][i].s + alpha * rR[k][i].ds; bar(rR[k][i], s);
-        t.theta += std::fabs((Ut[k][i] - Ut[k - 1][i]) - s);
+        t.theta += std::fabs((Ut[k][i] - Ut[k - 1][i]) - s - elastic(rR[k][i]));
       }
       if (k >= 1 && obs_node[k]) for (int j = 0; j < nobs; ++j) if (rO[k][j].on) {
         double s = rO[k][j].s + alpha * rO[k][j].ds; bar(rO[k][j], s);
-        t.theta += std::fabs(rowval(k, j, Xt[k]) - s);
+        t.theta += std::fabs(rowval(k, j, Xt[k]) - s - elastic(rO[k][j]));
       }
     }
     t.phi = phi;
@@ -728,23 +822,30 @@ struct Solver {
         if (it.ds > 0) a_pr = std::min(a_pr, tau_ * (it.U - it.s) / it.ds);
         if (it.dvU < 0) a_du = std::min(a_du, -tau_ * it.vU / it.dvU);
       }
+      if (it.el) {
+        if (it.dp < 0) a_pr = std::min(a_pr, -tau_ * it.p / it.dp);
+        if (it.dn < 0) a_pr = std::min(a_pr, -tau_ * it.n / it.dn);
+        if (it.dvp < 0) a_du = std::min(a_du, -tau_ * it.vp / it.dvp);
+        if (it.dvn < 0) a_du = std::min(a_du, -tau_ * it.vn / it.dvn);
+      }
     });
   }
 
   double dir_deriv(double mu_) {   // directional derivative of the barrier function along (dX, dU, ds)
     double dphi = 0;
     for (int k = 0; k <= N; ++k) {
-      if (k >= 1 && k < N) for (int i = 0; i < nx; ++i) dphi += os * 2 * c.Q[i] * (X[k][i] - xs[i]) * dX[k][i];
+      if (k >= 1) for (int i = 0; i < nx; ++i) dphi += osc * 2 * Qc[k][i] * (X[k][i] - Xr[k][i]) * dX[k][i];
       if (k < N) for (int i = 0; i < NU; ++i) {
-        dphi += os * 2 * c.R[i] * U[k][i] * dU[k][i];
-        if (k > 0 || c.du0_cost) {
+        dphi += osc * 2 * Rc[k][i] * (U[k][i] - Ur[k][i]) * dU[k][i];
+        if (du_cost(k)) {
           double d = U[k][i] - (k ? U[k - 1][i] : c.u_last[i]);
-          dphi += os * 2 * c.DR[i] * d * (dU[k][i] - (k ? dU[k - 1][i] : 0.0));
+          dphi += osc * 2 * DRc[i] * d * (dU[k][i] - (k ? dU[k - 1][i] : 0.0));
         }
       }
       each_item(k, [&](Ineq& it) {
         if (it.hasL) dphi -= mu_ * it.ds / (it.s - it.L);
         if (it.hasU) dphi += mu_ * it.ds / (it.U - it.s);
+        if (it.el) dphi += (rho - mu_ / it.p) * it.dp + (rho - mu_ / it.n) * it.dn;
       });
     }
     return dphi;
@@ -786,6 +887,7 @@ struct Solver {
         it.s += alpha * it.ds;
         if (it.hasL) it.vL += alpha_du * it.dvL;
         if (it.hasU) it.vU += alpha_du * it.dvU;
+        if (it.el) { it.p += alpha * it.dp; it.n += alpha * it.dn; it.vp += alpha_du * it.dvp; it.vn += alpha_du * it.dvn; }
       });
     }
     // boxes: slack is the variable itself
@@ -795,8 +897,182 @@ struct Solver {
       each_item(k, [&](Ineq& it) {   // IPOPT eq. (16): keep Sigma within kappa_Sigma of mu / slack^2
         if (it.hasL) { double d = it.s - it.L; it.vL = std::max(std::min(it.vL, o.kappa_sigma * mu_ / d), mu_ / (o.kappa_sigma * d)); }
         if (it.hasU) { double d = it.U - it.s; it.vU = std::max(std::min(it.vU, o.kappa_sigma * mu_ / d), mu_ / (o.kappa_sigma * d)); }
+        if (it.el) {
+          it.vp = std::max(std::min(it.vp, o.kappa_sigma * mu_ / it.p), mu_ / (o.kappa_sigma * it.p));
+          it.vn = std::max(std::min(it.vn, o.kappa_sigma * mu_ / it.n), mu_ / (o.kappa_sigma * it.n));
+        }
       });
     }
+  }
+
+  // ----- one interior-point iteration of the current phase (main or restoration) --------------------------------
+  // false: no acceptable step (status_fail says why)
+  bool ip_iteration(double mu_floor, int& status_fail) {
+    double a_pr, a_du, alpha = 0, dphi = 0; bool armijo_type = false;
+    // barrier parameter update (monotone, Fiacco-McCormick)
+    const double mu_before = mu;
+    for (;;) {
+      Err em = kkt_error(mu);
+      if (Emu(em) <= o.kappa_eps * mu && mu > mu_floor) {
+        mu = std::max(mu_floor, std::min(o.kappa_mu * mu, std::pow(mu, o.theta_mu)));
+        tau = std::max(o.tau_min, 1.0 - mu);
+        filter.clear();
+      } else break;
+    }
+    // the proximity weight of the restoration problem follows mu: zeta = sqrt(mu)
+    if (resto && mu != mu_before) { set_resto_cost(std::sqrt(mu)); fval = objective(X, U) + elastic_cost(); }
+    if (!factorize()) { status_fail = MPCB_ST_NUMERIC; return false; }
+    set_targets(mu);
+    solve_direction();
+    step_lengths(tau, a_pr, a_du);
+    dphi = dir_deriv(mu);
+    alpha = line_search(a_pr, mu, dphi, armijo_type);
+    if (debug) std::fprintf(stderr, "%s %3d mu %.2e E0 %.3e th %.3e f %.8e a_pr %.3e a %.3e a_du %.3e dw %.1e dphi %.2e |F|=%zu\n", resto ? "R " : "it",
+                            iters, mu, err0, theta, fval, a_pr, alpha, a_du, dw_used, dphi, filter.size());
+    if (debug) {   // the item that limits the primal step
+      double best = 2; const Ineq* bi = nullptr; int bk = -1; const char* what = "";
+      for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) {
+        auto upd = [&](double a, const char* w) { if (a < best) { best = a; bi = &it; bk = k; what = w; } };
+        if (it.hasL && it.ds < 0) upd(-(it.s - it.L) / it.ds, "sL");
+        if (it.hasU && it.ds > 0) upd((it.U - it.s) / it.ds, "sU");
+        if (it.el && it.dp < 0) upd(-it.p / it.dp, "p");
+        if (it.el && it.dn < 0) upd(-it.n / it.dn, "n");
+      });
+      if (bi) std::fprintf(stderr, "      block %s: node %d idx(%d,%d) s-L %.3e U-s %.3e ds %.3e vL %.3e vU %.3e r %.3e p %.2e n %.2e dp %.2e dn %.2e\n", what, bk, bi->i0, bi->i1,
+                           bi->s - bi->L, bi->U - bi->s, bi->ds, bi->vL, bi->vU, bi->r, bi->p, bi->n, bi->dp, bi->dn);
+    }
+    last_alpha = alpha; last_apr = a_pr;
+    if (!(alpha > 0)) { status_fail = MPCB_ST_LINESEARCH; return false; }
+    if (!armijo_type) filter.emplace_back((1 - o.gamma_theta) * theta, barrier_phi(fval, mu) - o.gamma_phi * theta);
+    apply_step(alpha, a_du, mu);
+    eval_point();
+    if (!std::isfinite(theta) || !std::isfinite(fval)) { status_fail = MPCB_ST_NUMERIC; return false; }
+    return true;
+  }
+  double last_alpha = 0, last_apr = 0, slow_theta0 = 0;
+  int slow_run = 0, trips = 0;
+
+  // violation of the ORIGINAL constraints at the iterate: shooting defects and  c(w) - s  of the general rows (l1 and max norm)
+  void original_violation(double& th1, double& thinf) {
+    th1 = 0; thinf = 0;
+    for (int k = 0; k < N; ++k) for (int i = 0; i < nx; ++i) { th1 += std::fabs(dfc[k][i]); thinf = std::max(thinf, std::fabs(dfc[k][i])); }
+    for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) {
+      const double r0 = it.r + (it.el ? it.p - it.n : 0.0);
+      th1 += std::fabs(r0); thinf = std::max(thinf, std::fabs(r0));
+    });
+  }
+
+  // ----- restoration phase (Waechter & Biegler 2006, section 3.3, on the stage-structured problem) ----------------------
+  //   min  rho sum_i (p_i + n_i) + zeta/2 ||D_R (w - w_R)||^2      zeta = sqrt(mu), D_R = diag(1 / max(1, |w_R|)), rho = 1000
+  //   s.t. X_{k+1} = F(X_k, U_k)                                    shooting rows stay hard
+  //        c_i(w) - s_i - p_i + n_i = 0,  L <= s <= U,  p, n >= 0   general rows (rate, obstacle) elastic
+  //        boxes on U and X as they are
+  // solved by the same interior-point iteration (own filter, own mu, starting at max(mu, ||violation||_inf); p, n initialised
+  // from the residuals as in IPOPT eq. (33); bound multipliers capped at rho; equality multipliers 0).  Leaves
+  //   0  with an iterate acceptable to the main filter (augmented with the entry point) whose original violation is <= 0.9 of the
+  //      violation at entry: the main phase continues from it (mu of the main phase, lam = 0, bound duals kept if <= 1000 else 1);
+  //   MPCB_ST_INFEASIBLE   the restoration problem itself is solved to tol and the original violation is still > tol: a
+  //      stationary point of the l1 violation = LOCAL infeasibility;
+  //   MPCB_ST_RESTO_FAILED / MPCB_ST_MAXITER / MPCB_ST_NUMERIC otherwise.
+  int restoration() {
+    ++n_resto_calls;
+    const double mu_main = mu;
+    // Entry.  The slacks of the general rows (rate, obstacle) are auxiliary variables; after a stalled main phase they lag behind
+    // the row values or sit pinned at a bound.  They are re-initialised from w exactly as at a fresh start (row value pushed
+    // inside its bounds), and the entry pair (theta, phi) of the main filter is evaluated there.  The main filter restarts from
+    // that pair alone.  (So the whole state the phase starts from is w, mu and the filter bounds: that is what the HIP kernel
+    // hands from its first pass to its restoration pass.)
+    for (int k = 0; k <= N; ++k) {
+      auto fresh = [&](Ineq& it) { if (it.on) { const double cval = it.r + it.s; it.s = push(it, cval); } };
+      if (k >= 1 && k < N) for (int i = 0; i < NU; ++i) fresh(rR[k][i]);
+      if (k >= 1 && obs_node[k]) for (int j = 0; j < nobs; ++j) fresh(rO[k][j]);
+    }
+    eval_point();
+    double th_entry, thinf_entry; original_violation(th_entry, thinf_entry);
+    const double phi_entry = barrier_phi(fval, mu_main);
+    std::vector<std::pair<double, double>> filter_main;
+    filter_main.emplace_back((1 - o.gamma_theta) * th_entry, phi_entry - o.gamma_phi * th_entry);
+    const double theta_max_main = theta_max, theta_min_main = theta_min;
+    // the restoration problem: obstacle rows elastic (the reverse-convex rows are what can make an instance infeasible; rate rows
+    // and boxes are linear and jointly satisfiable, they stay as they are), p, n from the residuals (IPOPT eq. (33)), every
+    // bound dual centred at mu / distance and capped at rho
+    resto = true;
+    std::memcpy(XR, X, sizeof XR); std::memcpy(UR, U, sizeof UR);
+    mu = std::max(mu_main, thinf_entry);
+    tau = std::max(o.tau_min, 1.0 - mu);
+    set_resto_cost(std::sqrt(mu));
+    for (int k = 0; k <= N; ++k) {
+      if (k >= 1 && obs_node[k]) for (int j = 0; j < nobs; ++j) {
+        Ineq& it = rO[k][j];
+        if (!it.on) continue;
+        const double r0 = it.r, a = (mu - rho * r0) / (2 * rho);
+        it.el = true;
+        it.n = a + std::sqrt(a * a + mu * r0 / (2 * rho)); it.p = r0 + it.n;
+        it.vp = mu / it.p; it.vn = mu / it.n;
+      }
+      each_item(k, [&](Ineq& it) {
+        if (it.hasL) it.vL = std::min(rho, mu / (it.s - it.L));
+        if (it.hasU) it.vU = std::min(rho, mu / (it.U - it.s));
+      });
+    }
+    std::memset(lam, 0, sizeof lam);
+    filter.clear();
+    eval_point();
+    theta_max = 1e4 * std::max(1.0, theta); theta_min = 1e-4 * std::max(1.0, theta);
+    const double mu_floor = c.tol / (o.kappa_eps + 1.0);
+    int rc = -1;
+    for (int rit = 0;; ++rit, ++iters, ++n_resto_iters) {
+      if (++trips > 3 * c.max_iter + 50) { rc = MPCB_ST_RESTO_FAILED; break; }
+      // did the restoration do its job?  (original violation and original barrier function at this iterate)
+      double th1, thinf; original_violation(th1, thinf);
+      if (rit >= 1 && th1 <= o.resto_kappa * th_entry && th1 <= theta_max_main) {
+        const bool was = resto; resto = false; set_main_cost();
+        double phi_o = os * objective(X, U);
+        for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) {
+          if (it.hasL) phi_o -= mu_main * std::log(it.s - it.L);
+          if (it.hasU) phi_o -= mu_main * std::log(it.U - it.s);
+        });
+        resto = was; set_resto_cost(std::sqrt(mu));
+        bool okf = true;
+        for (auto& e : filter_main) if (th1 >= e.first && phi_o >= e.second) okf = false;
+        if (okf) { rc = 0; break; }
+      }
+      Err e0 = kkt_error(0.0);
+      err0 = Emu(e0);
+      // the restoration problem itself is solved: violated rows -> locally infeasible; a feasible point that the main phase could
+      // not leave (no restoration step was taken) -> the restoration has nothing to offer (IPOPT: Restoration_Failed)
+      if (err0 <= c.tol) { rc = (thinf > c.tol) ? MPCB_ST_INFEASIBLE : (rit == 0 ? MPCB_ST_RESTO_FAILED : 0); break; }
+      // Local-infeasibility certificate without driving mu to 1e-9.  Once the barrier subproblem of the current mu is solved
+      // (the test that lets mu decrease) and the hard rows (shooting, rate) are satisfied to a small fraction of it, the elastic
+      // violation V = sum (p + n) at this iterate exceeds the locally minimal one by at most the barrier duality gap n_v mu / rho
+      // plus what the proximity term can buy, (n_w / 2) sqrt(mu) / rho.  If V is larger than that (with a safety factor), no
+      // nearby point satisfies the obstacle rows.
+      {
+        Err em = kkt_error(mu);
+        int n_v = 0, n_w = nx * N + NU * N;
+        double V = 0;
+        for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) { n_v += (it.hasL ? 1 : 0) + (it.hasU ? 1 : 0) + (it.el ? 2 : 0); if (it.el) V += it.p + it.n; });
+        const double gap = (o.gap_safety * n_v * mu + 0.5 * n_w * std::sqrt(mu)) / rho;
+        if (Emu(em) <= o.kappa_eps * mu && V > gap + 1e-6 && theta <= 0.01 * V) { rc = MPCB_ST_INFEASIBLE; break; }
+      }
+      if (iters >= c.max_iter) { rc = MPCB_ST_MAXITER; break; }
+      int why = MPCB_ST_RESTO_FAILED;
+      if (!ip_iteration(mu_floor, why)) { rc = (why == MPCB_ST_LINESEARCH) ? MPCB_ST_RESTO_FAILED : why; break; }
+    }
+    // back to the main problem (also on failure: the outputs are those of the original NLP)
+    resto = false; set_main_cost();
+    double vmax = 0;
+    for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) {
+      it.el = false; it.p = it.n = it.vp = it.vn = it.dp = it.dn = 0;
+      if (it.hasL) vmax = std::max(vmax, it.vL);
+      if (it.hasU) vmax = std::max(vmax, it.vU);
+    });
+    if (vmax > 1000.0) for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) { if (it.hasL) it.vL = 1.0; if (it.hasU) it.vU = 1.0; });
+    std::memset(lam, 0, sizeof lam);
+    mu = mu_main; tau = std::max(o.tau_min, 1.0 - mu);
+    filter = filter_main; theta_max = theta_max_main; theta_min = theta_min_main;
+    eval_point();
+    return rc;
   }
 
   // ----- main loop ------------------------------------------------------------------------------------------
@@ -806,46 +1082,26 @@ struct Solver {
     const double mu_floor = c.tol / (o.kappa_eps + 1.0);
     status = MPCB_ST_MAXITER;
     for (iters = 0;; ++iters) {
+      if (++trips > 3 * c.max_iter + 50) { status = MPCB_ST_RESTO_FAILED; break; }   // phase changes are not iterations: bound them too
       Err e0 = kkt_error(0.0);
       err0 = Emu(e0);
       if (err0 <= c.tol) { status = MPCB_ST_SOLVED; break; }
       if (iters >= c.max_iter) { status = MPCB_ST_MAXITER; break; }
-      if (!factorize()) { status = MPCB_ST_NUMERIC; break; }
-
-      double a_pr, a_du, alpha = 0, dphi = 0; bool armijo_type = false;
-      // barrier parameter update (monotone, Fiacco-McCormick)
-      for (;;) {
-        Err em = kkt_error(mu);
-        if (Emu(em) <= o.kappa_eps * mu && mu > mu_floor) {
-          mu = std::max(mu_floor, std::min(o.kappa_mu * mu, std::pow(mu, o.theta_mu)));
-          tau = std::max(o.tau_min, 1.0 - mu);
-          filter.clear();
-        } else break;
+      int why = MPCB_ST_LINESEARCH;
+      const double th_before = theta;
+      if (ip_iteration(mu_floor, why)) {
+        // early entry into restoration: trig_k accepted steps in a row shorter than trig_alpha that together reduced the violation
+        // by less than the factor trig_theta (a slack pinned at its bound with the row still violated: the pattern of an
+        // infeasible instance; IPOPT itself waits for the line search to fail, dozens of such steps later)
+        if (last_alpha < o.trig_alpha && theta > 1e-6) { if (slow_run == 0) slow_theta0 = th_before; ++slow_run; } else slow_run = 0;
+        if (!(c.restoration && o.trig_k > 0 && slow_run >= o.trig_k && theta > o.trig_theta * slow_theta0)) continue;
+        ++iters;                         // this iteration was completed
       }
-      set_targets(mu);
-      solve_direction();
-      step_lengths(tau, a_pr, a_du);
-      dphi = dir_deriv(mu);
-      alpha = line_search(a_pr, mu, dphi, armijo_type);
-      if (debug) std::fprintf(stderr, "it %3d mu %.2e E0 %.3e th %.3e f %.8e a_pr %.3e a %.3e a_du %.3e dw %.1e dphi %.2e |F|=%zu\n",
-                              iters, mu, err0, theta, fval, a_pr, alpha, a_du, dw_used, dphi, filter.size());
-      if (debug) {
-        // report the blocking item
-        double best = 2; const Ineq* bi = nullptr; int bk = -1;
-        for (int k = 0; k <= N; ++k) each_item(k, [&](Ineq& it) {
-          double a = 2;
-          if (it.hasL && it.ds < 0) a = std::min(a, -(it.s - it.L) / it.ds);
-          if (it.hasU && it.ds > 0) a = std::min(a, (it.U - it.s) / it.ds);
-          if (a < best) { best = a; bi = &it; bk = k; }
-        });
-        if (bi) std::fprintf(stderr, "      block: node %d idx(%d,%d) s-L %.3e U-s %.3e ds %.3e vL %.3e vU %.3e r %.3e tL %.2e tU %.2e\n", bk, bi->i0, bi->i1,
-                             bi->s - bi->L, bi->U - bi->s, bi->ds, bi->vL, bi->vU, bi->r, bi->tL, bi->tU);
-      }
-      if (!(alpha > 0)) { status = MPCB_ST_LINESEARCH; break; }
-      if (!armijo_type) filter.emplace_back((1 - o.gamma_theta) * theta, barrier_phi(fval, mu) - o.gamma_phi * theta);
-      apply_step(alpha, a_du, mu);
-      eval_point();
-      if (!std::isfinite(theta) || !std::isfinite(fval)) { status = MPCB_ST_NUMERIC; break; }
+      slow_run = 0;
+      if (why != MPCB_ST_LINESEARCH || !c.restoration) { status = why; break; }
+      const int rc = restoration();      // counts its iterations in `iters`
+      if (rc != 0) { status = rc; break; }
+      --iters;                           // the for-increment belongs to an iteration; the hand-over itself is none
     }
   }
 
@@ -856,9 +1112,9 @@ struct Solver {
       for (int k = 0; k < N; ++k) for (int i = 0; i < NU; ++i) z[NU * k + i] = U[k][i];
       for (int k = 0; k <= N; ++k) for (int i = 0; i < nx; ++i) z[NU * N + nx * k + i] = X[k][i];
     }
-    if (obj) *obj = objective(X, U);
+    if (obj) { set_main_cost(); *obj = objective(X, U); }
     if (st) *st = status;
-    if (std::getenv("MPCO_STATS")) std::fprintf(stderr, "STATS %d %d %d %d\n", status, iters, n_factor, n_trial);
+    if (std::getenv("MPCO_STATS")) std::fprintf(stderr, "STATS %d %d %d %d %d %d\n", status, iters, n_factor, n_trial, n_resto_calls, n_resto_iters);
     if (it) *it = iters;
     if (kkt) {
       double du = 0; Err e = kkt_error(0.0, &du);
@@ -915,6 +1171,8 @@ int check_cfg(const mpcb_config* c) {
   if (!(c->T > 0) || !(c->tol > 0) || c->max_iter < 0) return MPCB_E_INVALID;
   if (c->obs_mode == MPCB_OBS_DCBF && !(c->gamma > 0.0 && c->gamma <= 1.0 + 1e-12)) return MPCB_E_INVALID;
   if (c->obs_mode == MPCB_OBS_DCBF && c->gamma < 1.0 - 1e-12 && (c->model != MPCB_MODEL_KIN || c->obs_terminal)) return MPCB_E_UNSUPPORTED;
+  if (c->obs_mode == MPCB_OBS_DCBF && c->obs_terminal) return MPCB_E_UNSUPPORTED;
+  if (c->integrator != MPCB_INT_EULER) return c->integrator == MPCB_INT_RK4 ? MPCB_E_UNSUPPORTED : MPCB_E_INVALID;
   return MPCB_OK;
 }
 
@@ -932,7 +1190,7 @@ int mpco_default_config(mpcb_config* cfg, int32_t model, int32_t N, double T) {
   mpcb_config& c = *cfg;
   c.struct_size = sizeof(mpcb_config); c.model = model; c.N = N; c.T = T;
   c.n_obs = 0; c.obs_mode = MPCB_OBS_KEEPOUT; c.gamma = 1.0; c.max_iter = 100;
-  c.mu_strategy = MPCB_MU_MONOTONE; c.init_rollout = 0;
+  c.mu_strategy = MPCB_MU_MONOTONE; c.init_rollout = 0; c.integrator = MPCB_INT_EULER; c.restoration = 1;
   const double deg = M_PI / 180.0;
   for (int i = 0; i < NXM; ++i) { c.x_lo[i] = -INF; c.x_hi[i] = INF; }
   c.u_lo[0] = -35 * deg; c.u_hi[0] = 35 * deg; c.u_lo[1] = -3.0; c.u_hi[1] = 3.0;   // mpc_parameters.yaml:34-37

@@ -20,7 +20,8 @@ template <int NOBS>
 static void run_instance(const MpcbKArgs& a, int b) {
   using namespace mpcbk;
   const bool dyn = a.cfg.model == MPCB_MODEL_DYN;
-  const int total = dyn ? layout_dyn(a.cfg.N).total : layout_kin(a.cfg.N, a.nz).total;
+  const bool rp = a.pass == 1;                                    // restoration pass: the RESTO instantiations (kin only so far)
+  const int total = dyn ? layout_dyn(a.cfg.N).total : layout_kin(a.cfg.N, a.nz, rp).total;
   std::vector<double> lds(total + 64, 0.0);
   std::barrier<> bar(64);
   wv::Emu emu; emu.bar = &bar;
@@ -30,7 +31,9 @@ static void run_instance(const MpcbKArgs& a, int b) {
       wv::t_lane = l; wv::t_emu = &emu;
       const bool gen = !dyn && a.cfg.obs_mode == MPCB_OBS_DCBF && a.cfg.gamma < 1.0 - 1e-12 && NOBS > 0;   // as mpcb_api.hip dispatches
       if (dyn) mpcb_solve_dyn<NOBS>(a, b, lds.data());
+      else if (gen && rp) mpcb_solve_kin<(NOBS > 0 ? NOBS : 1), true, true>(a, b, lds.data());
       else if (gen) mpcb_solve_kin<(NOBS > 0 ? NOBS : 1), true>(a, b, lds.data());
+      else if (rp) mpcb_solve_kin<NOBS, false, true>(a, b, lds.data());
       else mpcb_solve_kin<NOBS>(a, b, lds.data());
     });
   for (auto& t : th) t.join();
@@ -43,18 +46,26 @@ extern "C" int mpcb_emu_solve(const mpcb_config* cfg, int32_t B, const double* x
   const int nx = cfg->model == MPCB_MODEL_DYN ? 6 : 4;
   int nrate = 0;
   for (int i = 0; i < 2; ++i) if (cfg->du_lo[i] > -1e300 || cfg->du_hi[i] < 1e300) ++nrate;
-  MpcbKArgs a;
+  MpcbKArgs a{};
+  a.st_stride = 1;
   a.cfg = *cfg; a.B = B; a.obs_kind = obs_kind; a.want_mult = (lam_g || lam_x) ? 1 : 0; a.trace_instance = trace_instance;
   a.nz = 2 * cfg->N + nx * (cfg->N + 1);
   a.ng = nx * (cfg->N + 1) + nrate * (cfg->N - 1) + cfg->n_obs * (cfg->obs_terminal ? cfg->N + 1 : cfg->N);
   a.x0 = x0; a.xs = xs; a.obs = obs; a.z0 = z0; a.z = z; a.obj = obj; a.kkt = kkt; a.lam_g = lam_g; a.lam_x = lam_x;
   a.status = status; a.iters = iters; a.trace = trace;
-  for (int b = 0; b < B; ++b) {
-    if (cfg->n_obs == 0) run_instance<0>(a, b);
-    else if (cfg->n_obs == 1) run_instance<1>(a, b);
-    else if (cfg->n_obs <= 3) run_instance<3>(a, b);
-    else if (cfg->n_obs <= 8) run_instance<8>(a, b);
-    else return MPCB_E_UNSUPPORTED;
+  std::vector<double> work((size_t)B * mpcbk::WK_SIZE, 0.0);
+  const bool two_pass = cfg->restoration && cfg->model == MPCB_MODEL_KIN;      // as mpcb_api.hip: first pass, then the restoration pass
+  a.work = two_pass ? work.data() : nullptr;
+  for (int pass = 0; pass < (two_pass ? 2 : 1); ++pass) {
+    a.pass = pass;
+    for (int b = 0; b < B; ++b) {
+      if (pass == 1 && status[b] != MPCB_ST_NEEDS_RESTO) continue;
+      if (cfg->n_obs == 0) run_instance<0>(a, b);
+      else if (cfg->n_obs == 1) run_instance<1>(a, b);
+      else if (cfg->n_obs <= 3) run_instance<3>(a, b);
+      else if (cfg->n_obs <= 8) run_instance<8>(a, b);
+      else return MPCB_E_UNSUPPORTED;
+    }
   }
   return MPCB_OK;
 }

@@ -93,6 +93,9 @@ def test_edge_cases():
     assert r["status"][0] == _abi.ST_INFEASIBLE_X0
     # unavoidable collision: ends with a failure status, finite output, no hang
     r = oracle.solve(cfg, [[40.0, 3.5, 0, 25]], xs, scenes.SHIPPED_OBS[None])
+    assert r["status"][0] == _abi.ST_INFEASIBLE and r["iters"][0] <= 40 and np.all(np.isfinite(r["z"]))   # restoration: local infeasibility
+    off = product_cfg(); off.restoration = 0
+    r = oracle.solve(off, [[40.0, 3.5, 0, 25]], xs, scenes.SHIPPED_OBS[None])
     assert r["status"][0] in (_abi.ST_LINESEARCH, _abi.ST_MAXITER, _abi.ST_NUMERIC) and np.all(np.isfinite(r["z"]))
     # shortest and longest horizons
     for N in (1, 2, 63):
@@ -122,6 +125,29 @@ def test_edge_cases():
     bad = product_cfg(30, 1); bad.obs_mode = _abi.OBS_DCBF; bad.gamma = 1.5
     with pytest.raises(Exception):
         oracle.solve(bad, scenes.SHIPPED_X0[None], xs, scenes.SHIPPED_OBS[None])
+
+
+def test_restoration_phase_rescues_and_classifies():
+    """The restoration phase (Solver::restoration) on a seeded C2 batch: every instance the main phase alone solves is still
+    solved, some of the others are rescued, the rest end as locally infeasible (never with MPCB_ST_LINESEARCH), and instances
+    that never enter the phase are bit-identical.  IPOPT-default-like settings, which stall on most random scenes without it,
+    reach the product settings' points with it."""
+    x0, xs, obs = scenes.sample_c2(1024, seed=1)
+    off = product_cfg(); off.restoration = 0
+    a = oracle.solve(off, x0, xs, obs, want_multipliers=False); b = oracle.solve(product_cfg(), x0, xs, obs, want_multipliers=False)
+    ok_a, ok_b = a["status"] == 0, b["status"] == 0
+    assert (ok_a & ~ok_b).sum() == 0 and (~ok_a & ok_b).sum() >= 8
+    assert not np.isin(b["status"], (_abi.ST_LINESEARCH,)).any() and (b["status"] == _abi.ST_INFEASIBLE).sum() >= 100
+    ident = ok_a & ok_b & (a["z"] == b["z"]).all(axis=1) & (a["iters"] == b["iters"])      # never entered the phase: same arithmetic
+    assert ident.sum() >= 0.85 * ok_a.sum()
+    assert b["iters"][~ok_b].mean() <= 32 and b["iters"].sum() <= 1.12 * a["iters"].sum()
+    # every locally-infeasible instance really violates an obstacle row or was pushed against a box: the returned point is
+    # dynamics-feasible (hard rows) and finite
+    assert np.all(np.isfinite(b["z"]))
+    ipopt_like = oracle.default_config(N=30, n_obs=1)               # mu_init 0.1, start as given, restoration on
+    c = oracle.solve(ipopt_like, x0[:256], xs[:256], obs[:256], want_multipliers=False)
+    both = (c["status"] == 0) & ok_b[:256]
+    assert both.sum() >= 0.6 * ok_b[:256].sum() and np.median(np.abs(c["z"][both] - b["z"][:256][both]).max(axis=1)) <= 1e-6
 
 
 def test_hand_written_kinematic_derivatives_equal_ad():
