@@ -42,6 +42,12 @@ __global__ __launch_bounds__(64, MPCB_WAVES_PER_SIMD) void mpcb_kernel_dyn(const
   mpcb_solve_dyn<NOBS>(a, (int)blockIdx.x, mpcb_lds);
 }
 
+template <int NOBS>
+__global__ __launch_bounds__(64, 1) void mpcb_kernel_dyn_resto(const MpcbKArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double mpcb_lds[];
+  mpcb_solve_dyn<NOBS, true>(a, (int)blockIdx.x, mpcb_lds);
+}
+
 // f(x,u) of the configured model: the reference's `mpc_solver.f` (kin.py:153-159, dyn.py:156-177); host and device
 __host__ __device__ inline void model_rhs(const mpcb_config& c, const double* x, const double* u, double* xdot) {
 #pragma clang fp contract(off)   // every product and sum rounded on its own, as numpy / CasADi evaluate the reference's expressions
@@ -195,8 +201,6 @@ int check_cfg(mpcb_handle* h, const mpcb_config* c) {
     return fail(h, MPCB_E_UNSUPPORTED, "MPCB_INT_RK4: the reference's NLP and plant are explicit Euler (kin.py:207); no RK4 mode is built");
   if (c->integrator != MPCB_INT_EULER) return fail(h, MPCB_E_INVALID, "unknown integrator %d", c->integrator);
   if (c->restoration != 0 && c->restoration != 1) return fail(h, MPCB_E_INVALID, "restoration must be 0 or 1");
-  if (c->restoration && c->model == MPCB_MODEL_DYN)
-    return fail(h, MPCB_E_UNSUPPORTED, "the restoration phase is implemented for the kinematic model; set restoration = 0 for MPCB_MODEL_DYN");
   if (std::isfinite(c->x_lo[0]) || std::isfinite(c->x_hi[0]) || std::isfinite(c->x_lo[2]) || std::isfinite(c->x_hi[2]))
     return fail(h, MPCB_E_UNSUPPORTED, "state boxes are supported on y, vx (and vy for the dynamic model) (kin.py:97-105, dyn.py:97-110)");
   if (c->model == MPCB_MODEL_KIN) {
@@ -293,10 +297,16 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in) {
   if (two_pass(h->cfg)) {
     // restoration pass over the same grid: instances that ended the first pass with MPCB_ST_NEEDS_RESTO continue, the others return
     a.pass = 1;
-    const size_t lds2 = (size_t)mpcbk::layout_kin(h->cfg.N, h->nz, true).total * sizeof(double);
+    const bool dyn = h->cfg.model == MPCB_MODEL_DYN;
+    const size_t lds2 = (size_t)(dyn ? mpcbk::layout_dyn(h->cfg.N, true).total : mpcbk::layout_kin(h->cfg.N, h->nz, true).total) * sizeof(double);
     if (lds2 > 160 * 1024) return fail(h, MPCB_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds2);
     const bool gen = h->cfg.obs_mode == MPCB_OBS_DCBF && h->cfg.gamma < 1.0 - 1e-12 && n > 0;
-    if (gen) {
+    if (dyn) {
+      if (n <= 1) rc = launch_kernel(h, mpcb_kernel_dyn_resto<1>, a, lds2);
+      else if (n <= 3) rc = launch_kernel(h, mpcb_kernel_dyn_resto<3>, a, lds2);
+      else if (n <= 5) rc = launch_kernel(h, mpcb_kernel_dyn_resto<5>, a, lds2);
+      else rc = launch_kernel(h, mpcb_kernel_dyn_resto<8>, a, lds2);
+    } else if (gen) {
       if (n == 1) rc = launch_kernel(h, mpcb_kernel_kin_resto<1, true>, a, lds2);
       else if (n <= 3) rc = launch_kernel(h, mpcb_kernel_kin_resto<3, true>, a, lds2);
       else rc = launch_kernel(h, mpcb_kernel_kin_resto<8, true>, a, lds2);
@@ -358,7 +368,7 @@ int mpcb_default_config(mpcb_config* cfg, int32_t model, int32_t N, double T) {
   c.struct_size = sizeof(mpcb_config);
   c.model = model; c.N = N; c.T = T; c.gamma = 1.0;
   c.obs_mode = MPCB_OBS_KEEPOUT; c.max_iter = 100;                       // kin.py:252
-  c.mu_strategy = MPCB_MU_MONOTONE; c.init_rollout = 1; c.integrator = MPCB_INT_EULER; c.restoration = (model == MPCB_MODEL_KIN) ? 1 : 0;
+  c.mu_strategy = MPCB_MU_MONOTONE; c.init_rollout = 1; c.integrator = MPCB_INT_EULER; c.restoration = 1;
   const double rad = M_PI / 180.0;
   for (int i = 0; i < MPCB_NX_MAX; ++i) { c.x_lo[i] = -INF; c.x_hi[i] = INF; }
   // mpc_parameters.yaml: kinematics_constraints / dynamics_constraints / vehicle_params / tire_params

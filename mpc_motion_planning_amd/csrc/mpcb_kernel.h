@@ -1280,6 +1280,9 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       if (!accepted) {
         if (RESTO && rs) { status = MPCB_ST_RESTO_FAILED; break; }                    // the restoration's own line search failed
         if (!c.restoration) { status = MPCB_ST_LINESEARCH; break; }
+        // failure at an (almost) feasible point = round-off in the end game: nothing to restore (IPOPT: "Restoration phase is called
+        // at point that is almost feasible" -> Restoration_Failed); the nearly converged iterate is returned as it is
+        if (e_prim <= c.tol) { status = MPCB_ST_RESTO_FAILED; break; }
         if (!RESTO) { hand_over(iters); break; }                                      // where IPOPT enters restoration
         enter = true; continue;
       }

@@ -36,8 +36,10 @@ enum DynEnt {
 constexpr int DPST = 66 /* P_k 8x8 + 2 pad slots for the stores of the lanes below the diagonal */, DPSS = 10, DFWS = 44, DFW_KFF = 16, DFW_A = 18, DFW_B = 32, DFW_D = 34, DFW_PAD = 40, DWSZ = 64, DWU = 16 + 16;
 // constant block (as in the kin kernel): cost weights, reference state and last control, read from LDS by the node-parallel phases
 constexpr int DCS_WQ = 0, DCS_WR = 6, DCS_WDR = 8, DCS_Q = 10, DCS_R = 16, DCS_DR = 18, DCS_UL = 20, DCS_XS = 22, DCSZ = 28;
-struct LayoutDyn { int ld, ent, Pst, pst, fw, W, Wu, cst, filt, zbuf, total; };
-MPCB_HD LayoutDyn layout_dyn(int N) {
+// per-node cost table of the RESTO instantiation, [row][64] (see CostRow in mpcb_kernel.h)
+enum DynCostRow { DCT_WQ = 0, DCT_XR = 6, DCT_WR = 12, DCT_UR = 14, DCT_QQ = 16, DCT_RR = 22, DCT_WDR = 24, DCT_DRR = 26, DCT_ROWS = 28 };
+struct LayoutDyn { int ld, ent, Pst, pst, fw, W, Wu, cst, filt, zbuf, ct, total; };
+MPCB_HD LayoutDyn layout_dyn(int N, bool resto = false) {
   LayoutDyn L;
   const int N1 = N + 1, NA = 8;
   L.ld = N1 | 1;
@@ -51,6 +53,7 @@ MPCB_HD LayoutDyn layout_dyn(int N) {
   L.filt = o; o += 2 * FILTER_MAX;
   L.ent = o; o += DYN_NENT * L.ld;
   L.zbuf = L.Pst;
+  L.ct = o; if (resto) o += DCT_ROWS * 64;
   L.total = o;
   return L;
 }
@@ -129,14 +132,16 @@ MPCB_DEV void dyn_hess(const mpcb_config& c, const double* X, const DynEval& e, 
 
 }  // namespace mpcbk
 
-template <int NOBS>
+// RESTO: the instantiation of the restoration pass (see mpcb_solve_kin)
+template <int NOBS, bool RESTO = false>
 MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   using namespace mpcbk;
-  constexpr int NX = 6, NA = 8, NW = 10, NOB = NOBS > 0 ? NOBS : 1;
+  constexpr int NX = 6, NA = 8, NW = 10, NOB = NOBS > 0 ? NOBS : 1, NEL = RESTO ? NOB : 1;
   const mpcb_config& c = a.cfg;
   const int N = c.N, lane = wv::lane(), k = lane;
   const int nz = a.nz, nobs = c.n_obs;
-  const LayoutDyn L = layout_dyn(N);
+  if (RESTO && a.status[(size_t)b * a.st_stride] != MPCB_ST_NEEDS_RESTO) return;     // wave-uniform: this instance is done
+  const LayoutDyn L = layout_dyn(N, RESTO);
   const int ld = L.ld;
   double* ent = lds + L.ent;
   const double T = c.T;
@@ -202,6 +207,16 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
     g = wv::uni(wv::max(g));
     os = wv::uni((g > c.max_gradient) ? c.max_gradient / g : 1.0);
   }
+  if (RESTO) {     // restoration pass: the iterate is what the first pass left in z (the scaling above is that of the user's start)
+    wv::sync();
+    for (int i = lane; i < nz; i += 64) zbuf[i] = a.z[(size_t)b * nz + i];
+    wv::sync();
+#pragma unroll
+    for (int i = 0; i < NU; ++i) U[i] = hasu ? zbuf[NU * k + i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) X[i] = isnode ? zbuf[NU * N + NX * k + i] : 0.0;
+    wv::sync();
+  }
   double* cst = lds + L.cst;
   if (lane == 0) {
 #pragma unroll
@@ -210,6 +225,55 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
     for (int i = 0; i < NU; ++i) { cst[DCS_WR + i] = os * 2 * c.R[i]; cst[DCS_WDR + i] = os * 2 * c.DR[i]; cst[DCS_R + i] = c.R[i]; cst[DCS_DR + i] = c.DR[i]; cst[DCS_UL + i] = c.u_last[i]; }
   }
   wv::sync();
+  // objective of the running phase: uniform constants (first pass) or the per-node table of the RESTO instantiation
+  double* ct = lds + L.ct;
+  double osc = os;
+  bool rs = false;
+  auto cWQ = [&](int i) { return RESTO ? ct[(DCT_WQ + i) * 64 + lane] : cst[DCS_WQ + i]; };
+  auto cXS = [&](int i) { return RESTO ? ct[(DCT_XR + i) * 64 + lane] : cst[DCS_XS + i]; };
+  auto cQQ = [&](int i) { return RESTO ? ct[(DCT_QQ + i) * 64 + lane] : cst[DCS_Q + i]; };
+  auto cWR = [&](int i) { return RESTO ? ct[(DCT_WR + i) * 64 + lane] : cst[DCS_WR + i]; };
+  auto cRR = [&](int i) { return RESTO ? ct[(DCT_RR + i) * 64 + lane] : cst[DCS_R + i]; };
+  auto cUR = [&](int i) { return RESTO ? ct[(DCT_UR + i) * 64 + lane] : 0.0; };
+  auto cWDR = [&](int i) { return RESTO ? ct[(DCT_WDR + i) * 64 + lane] : cst[DCS_WDR + i]; };
+  auto cDRR = [&](int i) { return RESTO ? ct[(DCT_DRR + i) * 64 + lane] : cst[DCS_DR + i]; };
+  auto write_main_cost = [&]() {         // dyn.py:189-225
+    if (RESTO) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        ct[(DCT_WQ + i) * 64 + lane] = hasu ? os * 2 * c.Q[i] : 0.0; ct[(DCT_QQ + i) * 64 + lane] = hasu ? c.Q[i] : 0.0;
+        ct[(DCT_XR + i) * 64 + lane] = xs[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        ct[(DCT_WR + i) * 64 + lane] = hasu ? os * 2 * c.R[i] : 0.0; ct[(DCT_RR + i) * 64 + lane] = hasu ? c.R[i] : 0.0;
+        ct[(DCT_UR + i) * 64 + lane] = 0.0;
+        ct[(DCT_WDR + i) * 64 + lane] = os * 2 * c.DR[i]; ct[(DCT_DRR + i) * 64 + lane] = c.DR[i];
+      }
+    }
+  };
+  auto write_resto_cost = [&](double zeta, bool fresh, const double* Xc, const double* Uc) {
+    if (RESTO) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        if (fresh) ct[(DCT_XR + i) * 64 + lane] = Xc[i];
+        const double d = 1.0 / fmax(1.0, fabs(ct[(DCT_XR + i) * 64 + lane]));
+        const double q = xnode ? 0.5 * zeta * d * d : 0.0;
+        ct[(DCT_QQ + i) * 64 + lane] = q; ct[(DCT_WQ + i) * 64 + lane] = 2 * q;
+      }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        if (fresh) ct[(DCT_UR + i) * 64 + lane] = Uc[i];
+        const double d = 1.0 / fmax(1.0, fabs(ct[(DCT_UR + i) * 64 + lane]));
+        const double q = hasu ? 0.5 * zeta * d * d : 0.0;
+        ct[(DCT_RR + i) * 64 + lane] = q; ct[(DCT_WR + i) * 64 + lane] = 2 * q;
+        ct[(DCT_WDR + i) * 64 + lane] = 0.0; ct[(DCT_DRR + i) * 64 + lane] = 0.0;
+      }
+    }
+  };
+  write_main_cost();
+  const bool xq = RESTO ? xnode : xcost;
+  const bool xobj = RESTO ? isnode : hasu;
   if (k == 0) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) X[i] = gx0[i];
@@ -241,7 +305,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   const bool ro_node = xnode && obs_node;
   const bool ducost = hasu && (k > 0 || c.du0_cost);     // (U_k - U_{k-1})' DR (.) present in stage k     dyn.py:221-224
 
-  if (c.init_rollout) {
+  if (!RESTO && c.init_rollout) {
     U[0] = hasu ? fmin(fmax(U[0], c.u_lo[0]), c.u_hi[0]) : 0.0;
     U[1] = hasu ? fmin(fmax(U[1], c.u_lo[1]), c.u_hi[1]) : 0.0;
 #pragma clang loop unroll(disable)
@@ -258,17 +322,22 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   }
 
   Item iU0{1, 1, 0, 0}, iU1{1, 1, 0, 0}, iY{1, 1, 0, 0}, iVx{1, 1, 0, 0}, iVy{1, 1, 0, 0}, iR0{1, 1, 0, 0}, iR1{1, 1, 0, 0};
-  if (bu0_on) U[0] = push_in(qU0, U[0], c.bound_push, c.bound_frac);
-  if (bu1_on) U[1] = push_in(qU1, U[1], c.bound_push, c.bound_frac);
-  if (by_on) X[1] = push_in(qY, X[1], c.bound_push, c.bound_frac);
-  if (bvx_on) X[3] = push_in(qVx, X[3], c.bound_push, c.bound_frac);
-  if (bvy_on) X[4] = push_in(qVy, X[4], c.bound_push, c.bound_frac);
+  if (!RESTO) {    // (the restoration pass starts from an interior iterate of the first pass)
+    if (bu0_on) U[0] = push_in(qU0, U[0], c.bound_push, c.bound_frac);
+    if (bu1_on) U[1] = push_in(qU1, U[1], c.bound_push, c.bound_frac);
+    if (by_on) X[1] = push_in(qY, X[1], c.bound_push, c.bound_frac);
+    if (bvx_on) X[3] = push_in(qVx, X[3], c.bound_push, c.bound_frac);
+    if (bvy_on) X[4] = push_in(qVy, X[4], c.bound_push, c.bound_frac);
+  }
   double Up0 = wv::shfl(U[0], k - 1), Up1 = wv::shfl(U[1], k - 1);
   double sR0 = 0, sR1 = 0, rR0 = 0, rR1 = 0;
   if (r0_on) sR0 = push_in(qR0, U[0] - Up0, c.bound_push, c.bound_frac);
   if (r1_on) sR1 = push_in(qR1, U[1] - Up1, c.bound_push, c.bound_frac);
   double sO[NOB], vO[NOB], iO[NOB], rO[NOB], gO0[NOB], gO1[NOB];
   bool ro_on[NOB];
+  double eP[NEL], eN[NEL], vP[NEL], vN[NEL];      // restoration phase: elastic variables of the obstacle rows and their duals
+#pragma unroll
+  for (int j = 0; j < NEL; ++j) { eP[j] = 0; eN[j] = 0; vP[j] = 0; vN[j] = 0; }
 #pragma unroll
   for (int j = 0; j < NOBS; ++j) {
     ro_on[j] = ro_node && j < nobs;
@@ -291,7 +360,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   double dfc[NX] = {0, 0, 0, 0, 0, 0};
   double theta = 0, fval = 0, logsum = 0;
 
-  auto eval_lane = [&](const double* Xa, const double* Ua, double sR0a, double sR1a, const double* sOa, const DynEval& e,
+  auto eval_lane = [&](const double* Xa, const double* Ua, double sR0a, double sR1a, const double* sOa, const double* pa, const double* na, const DynEval& e,
                        double* dfa, double& rR0a, double& rR1a, double* rOa, double& up0, double& up1, double& th, double& fl, double& prod) {
     bool ok = true;
     double Ft[NX]; dyn_F(c, Xa, Ua, e, Ft);
@@ -312,15 +381,29 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
     if (r0_on) { bar(qR0, sR0a); rR0a = (Ua[0] - up0) - sR0a; th += fabs(rR0a); }
     if (r1_on) { bar(qR1, sR1a); rR1a = (Ua[1] - up1) - sR1a; th += fabs(rR1a); }
 #pragma unroll
-    for (int j = 0; j < NOBS; ++j) { rOa[j] = 0; if (ro_on[j]) { bar(qO, sOa[j]); rOa[j] = hval(j, Xa[0], Xa[1]) - sOa[j]; th += fabs(rOa[j]); } }
+    for (int j = 0; j < NOBS; ++j) {
+      rOa[j] = 0;
+      if (ro_on[j]) {
+        bar(qO, sOa[j]); rOa[j] = hval(j, Xa[0], Xa[1]) - sOa[j];
+        if (RESTO && rs) {        // elastic row: residual of c - s - p + n, cost rho (p + n), barrier on p and n
+          const double pj = pa[j], nj = na[j];
+          ok = ok && (pj > 0) && (nj > 0); prod *= pj * nj;
+          rOa[j] -= pj - nj; fl += RS_RHO * (pj + nj);
+        }
+        th += fabs(rOa[j]);
+      }
+    }
     if (isnode && !(Xa[3] > 0)) ok = false;              // vx must stay positive where the model is evaluated
-    if (hasu) {
+    if (xobj) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { const double d = Xa[i] - cst[DCS_XS + i]; fl += cst[DCS_Q + i] * d * d; }
-      fl += cst[DCS_R] * Ua[0] * Ua[0] + cst[DCS_R + 1] * Ua[1] * Ua[1];
+      for (int i = 0; i < NX; ++i) { const double d = Xa[i] - cXS(i); fl += cQQ(i) * d * d; }
+    }
+    if (hasu) {
+      const double e0 = Ua[0] - cUR(0), e1 = Ua[1] - cUR(1);
+      fl += cRR(0) * e0 * e0 + cRR(1) * e1 * e1;
       if (ducost) {
         const double d0 = Ua[0] - (k ? up0 : cst[DCS_UL]), d1 = Ua[1] - (k ? up1 : cst[DCS_UL + 1]);
-        fl += cst[DCS_DR] * d0 * d0 + cst[DCS_DR + 1] * d1 * d1;
+        fl += cDRR(0) * d0 * d0 + cDRR(1) * d1 * d1;
       }
     }
     return ok;
@@ -408,22 +491,101 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   const double mu_floor = c.tol / (K_EPS + 1.0);
   double err0 = 0, e_dual = 0, e_prim = 0;
 
+  // restoration-phase state (see mpcb_solve_kin)
+  double mu_main = 0, tmax_main = 0, tmin_main = 0, fm_theta = 0, fm_phi = 0, th_entry = 0;
+  int rit = 0, slow_run = 0;
+  double slow_theta0 = 0;
+  bool enter = false;
+  double n_el = 0;
+  if (RESTO) {
+    double cnt = 0;
+#pragma unroll
+    for (int j = 0; j < NOBS; ++j) if (ro_on[j]) cnt += 1.0;
+    n_el = wv::uni(wv::sum(cnt));
+  }
+
   if (status != MPCB_ST_INFEASIBLE_X0) {
-    {
+#pragma unroll
+    for (int j = 0; j < NOBS; ++j) if (ro_on[j]) { gO0[j] = 2 * (X[0] - ox[j]) * ix2[j]; gO1[j] = 2 * (X[1] - oy[j]) * iy2[j]; }
+    if (!RESTO) {
       DynEval ev; dyn_eval(c, X, U, ev);
       double th, fl, prod;
-      eval_lane(X, U, sR0, sR1, sO, ev, dfc, rR0, rR1, rO, Up0, Up1, th, fl, prod);
+      eval_lane(X, U, sR0, sR1, sO, eP, eN, ev, dfc, rR0, rR1, rO, Up0, Up1, th, fl, prod);
       double sv[3] = {th, fl, log(prod)};
       wv::reduce<3, 0>(sv, nullptr);
       theta = wv::uni(sv[0]); fval = wv::uni(sv[1]); logsum = wv::uni(sv[2]);
       recips();
-#pragma unroll
-      for (int j = 0; j < NOBS; ++j) if (ro_on[j]) { gO0[j] = 2 * (X[0] - ox[j]) * ix2[j]; gO1[j] = 2 * (X[1] - oy[j]) * iy2[j]; }
+      theta_max = wv::uni(1e4 * fmax(1.0, theta)); theta_min = wv::uni(1e-4 * fmax(1.0, theta));
+    } else {
+      const double* wk = a.work + (size_t)b * WK_SIZE;
+      mu = wv::uni(wk[WK_MU]); tau = fmax(TAU_MIN, 1.0 - mu);
+      theta_max = wv::uni(wk[WK_THMAX]); theta_min = wv::uni(wk[WK_THMIN]);
+      iters = (int)wk[WK_ITERS]; dw_last = wv::uni(wk[WK_DW]);
+      enter = true;
     }
-    theta_max = wv::uni(1e4 * fmax(1.0, theta)); theta_min = wv::uni(1e-4 * fmax(1.0, theta));
 
+    int trips = 0;
 #pragma clang loop unroll(disable)
-    for (iters = 0;; ++iters) {
+    for (;;) {
+      if (++trips > 3 * c.max_iter + 50) { status = MPCB_ST_RESTO_FAILED; break; }
+      if (RESTO && enter) {
+        // ----- entry into the restoration phase (oracle: Solver::restoration; comments in mpcb_solve_kin) ----------------------
+        enter = false;
+        mu_main = mu; tmax_main = theta_max; tmin_main = theta_min;
+        rs = false; osc = os;
+        DynEval ev; dyn_eval(c, X, U, ev);
+        Up0 = wv::shfl(U[0], k - 1); Up1 = wv::shfl(U[1], k - 1);
+        if (r0_on) sR0 = push_in(qR0, U[0] - Up0, c.bound_push, c.bound_frac);
+        if (r1_on) sR1 = push_in(qR1, U[1] - Up1, c.bound_push, c.bound_frac);
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j) if (ro_on[j]) sO[j] = push_in(qO, hval(j, X[0], X[1]), c.bound_push, c.bound_frac);
+        double th, fl, prod;
+        eval_lane(X, U, sR0, sR1, sO, eP, eN, ev, dfc, rR0, rR1, rO, Up0, Up1, th, fl, prod);
+        double vi = fmax(fabs(rR0), fabs(rR1));
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j) vi = fmax(vi, fabs(rO[j]));
+        if (hasu) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) vi = fmax(vi, fabs(dfc[i]));
+        }
+        double sv[3] = {th, fl, log(prod)}, mv[1] = {vi};
+        wv::reduce<3, 1>(sv, mv);
+        th_entry = wv::uni(sv[0]);
+        const double phi_entry = os * wv::uni(sv[1]) - mu_main * wv::uni(sv[2]);
+        fm_theta = (1 - G_THETA) * th_entry; fm_phi = phi_entry - G_PHI * th_entry;
+        rs = true; osc = 1.0;
+        mu = wv::uni(fmax(mu_main, wv::uni(mv[0]))); tau = fmax(TAU_MIN, 1.0 - mu);
+        write_resto_cost(sqrt(mu), true, X, U);
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
+          const double r0 = rO[j], aa = (mu - RS_RHO * r0) / (2 * RS_RHO);
+          eN[j] = aa + sqrt(aa * aa + mu * r0 / (2 * RS_RHO)); eP[j] = r0 + eN[j];
+          vP[j] = mu / eP[j]; vN[j] = mu / eN[j];
+        }
+        recips();
+        auto centre = [&](const Bnd& q, Item& it) {
+          if (q.hasL) it.vL = fmin(RS_RHO, mu * it.iL);
+          if (q.hasU) it.vU = fmin(RS_RHO, mu * it.iU);
+        };
+        if (bu0_on) centre(qU0, iU0);
+        if (bu1_on) centre(qU1, iU1);
+        if (by_on) centre(qY, iY);
+        if (bvx_on) centre(qVx, iVx);
+        if (bvy_on) centre(qVy, iVy);
+        if (r0_on) centre(qR0, iR0);
+        if (r1_on) centre(qR1, iR1);
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j) if (ro_on[j]) vO[j] = fmin(RS_RHO, mu * iO[j]);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) lam[i] = 0.0;
+        nfilt = 0;
+        eval_lane(X, U, sR0, sR1, sO, eP, eN, ev, dfc, rR0, rR1, rO, Up0, Up1, th, fl, prod);
+        double sw[3] = {th, fl, log(prod)};
+        wv::reduce<3, 0>(sw, nullptr);
+        theta = wv::uni(sw[0]); fval = wv::uni(sw[1]); logsum = wv::uni(sw[2]);
+        theta_max = wv::uni(1e4 * fmax(1.0, theta)); theta_min = wv::uni(1e-4 * fmax(1.0, theta));
+        rit = 0; slow_run = 0;
+      }
       MPCB_STAMP(t_a);
       // tyre forces and trig at the iterate are recomputed here rather than kept across the line search (13 doubles/lane)
       DynEval ev; dyn_eval(c, X, U, ev);
@@ -437,11 +599,11 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         const double Un0 = wv::shfl(U[0], k + 1), Un1 = wv::shfl(U[1], k + 1);
         const double yR0 = r0_on ? item_y(qR0, iR0) : 0.0, yR1 = r1_on ? item_y(qR1, iR1) : 0.0;
         const double yR0n = wv::shfl(yR0, k + 1), yR1n = wv::shfl(yR1, k + 1);
-        double sum_lam = 0, sum_v = 0, svmax = 0, svmin = 1e300, prim = 0;
+        double sum_lam = 0, sum_v = 0, svmax = 0, svmin = 1e300, prim = 0, edual_el = 0, Vel = 0;
         if (xnode) {
-          if (k < N) {
+          if (RESTO || k < N) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) rX[i] += cst[DCS_WQ + i] * (X[i] - cst[DCS_XS + i]);
+            for (int i = 0; i < NX; ++i) rX[i] += cWQ(i) * (X[i] - cXS(i));
           }
 #pragma unroll
           for (int i = 0; i < NX; ++i) { rX[i] -= lam[i]; sum_lam += fabs(lam[i]); }
@@ -454,12 +616,12 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           }
         }
         if (hasu) {
-          rU[0] += cst[DCS_WR] * U[0]; rU[1] += cst[DCS_WR + 1] * U[1];
+          rU[0] += cWR(0) * (U[0] - cUR(0)); rU[1] += cWR(1) * (U[1] - cUR(1));
           if (ducost) {
-            rU[0] += cst[DCS_WDR] * (U[0] - (k ? Up0 : cst[DCS_UL]));
-            rU[1] += cst[DCS_WDR + 1] * (U[1] - (k ? Up1 : cst[DCS_UL + 1]));
+            rU[0] += cWDR(0) * (U[0] - (k ? Up0 : cst[DCS_UL]));
+            rU[1] += cWDR(1) * (U[1] - (k ? Up1 : cst[DCS_UL + 1]));
           }
-          if (k + 1 < N) { rU[0] -= cst[DCS_WDR] * (Un0 - U[0]); rU[1] -= cst[DCS_WDR + 1] * (Un1 - U[1]); }
+          if (k + 1 < N) { rU[0] -= cWDR(0) * (Un0 - U[0]); rU[1] -= cWDR(1) * (Un1 - U[1]); }
           rU[0] += J.b4 * ln[4] + J.b5 * ln[5]; rU[1] += T * ln[3];
           if (k + 1 < N) { rU[0] += yR0n; rU[1] += yR1n; }
         }
@@ -479,8 +641,14 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           rX[0] -= vO[j] * gO0[j]; rX[1] -= vO[j] * gO1[j];
           const double p = (sO[j] - qO.L) * vO[j]; svmax = fmax(svmax, p); svmin = fmin(svmin, p); sum_v += vO[j];
           prim = fmax(prim, fabs(rO[j]));
+          if (RESTO && rs) {
+            edual_el = fmax(edual_el, fmax(fabs(RS_RHO + vO[j] - vP[j]), fabs(RS_RHO - vO[j] - vN[j])));
+            const double cp_ = eP[j] * vP[j], cn_ = eN[j] * vN[j];
+            svmax = fmax(svmax, fmax(cp_, cn_)); svmin = fmin(svmin, fmin(cp_, cn_)); sum_v += vP[j] + vN[j];
+            Vel += eP[j] + eN[j];
+          }
         }
-        double dual = 0;
+        double dual = edual_el;
         if (xnode) {
 #pragma unroll
           for (int i = 0; i < NX; ++i) dual = fmax(dual, fabs(rX[i]));
@@ -490,28 +658,125 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
 #pragma unroll
           for (int i = 0; i < NX; ++i) prim = fmax(prim, fabs(dfc[i]));
         }
-        double ss[2] = {sum_lam, sum_v}, mm[4] = {dual, prim, svmax, -svmin};
-        wv::reduce<2, 4>(ss, mm);
+        double ss[3] = {sum_lam, sum_v, Vel}, mm[4] = {dual, prim, svmax, -svmin};
+        wv::reduce<RESTO ? 3 : 2, 4>(ss, mm);
         e_dual = wv::uni(mm[0]); e_prim = wv::uni(mm[1]);
         const double sv_hi = wv::uni(mm[2]), sv_lo = -wv::uni(mm[3]);
-        const double e_sd = fmax(S_MAX, (wv::uni(ss[0]) + wv::uni(ss[1])) / fmax(1.0, n_lam + n_v)) / S_MAX;
-        const double e_sc = fmax(S_MAX, wv::uni(ss[1]) / fmax(1.0, n_v)) / S_MAX;
+        const double n_vr = (RESTO && rs) ? n_v + 2 * n_el : n_v;
+        const double e_sd = fmax(S_MAX, (wv::uni(ss[0]) + wv::uni(ss[1])) / fmax(1.0, n_lam + n_vr)) / S_MAX;
+        const double e_sc = fmax(S_MAX, wv::uni(ss[1]) / fmax(1.0, n_vr)) / S_MAX;
         const double base = fmax(e_dual / e_sd, e_prim);
-        err0 = fmax(base, (n_v > 0 ? sv_hi : 0.0) / e_sc);
-        if (a.trace && b == a.trace_instance && lane == 0) {
+        err0 = fmax(base, (n_vr > 0 ? sv_hi : 0.0) / e_sc);
+        if (a.trace && b == a.trace_instance && lane == 0 && iters <= c.max_iter) {
           double* t = a.trace + (size_t)iters * 8;
           t[0] = mu; t[1] = err0; t[2] = theta; t[3] = fval;
         }
-        if (err0 <= c.tol) { status = MPCB_ST_SOLVED; break; }
-        if (iters >= c.max_iter) { status = MPCB_ST_MAXITER; break; }
+        if (!(RESTO && rs)) {
+          if (err0 <= c.tol) { status = MPCB_ST_SOLVED; break; }
+          if (iters >= c.max_iter) { status = MPCB_ST_MAXITER; break; }
+        } else {
+          // ----- restoration phase: violation of the ORIGINAL rows and the original barrier function at this iterate
+          double t1 = fabs(rR0) + fabs(rR1), fm = 0, pl = 1.0, ti = fmax(fabs(rR0), fabs(rR1));
+          if (hasu) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { t1 += fabs(dfc[i]); ti = fmax(ti, fabs(dfc[i])); }
+          }
+#pragma unroll
+          for (int j = 0; j < NOBS; ++j) if (ro_on[j]) { const double r0 = rO[j] + (eP[j] - eN[j]); t1 += fabs(r0); ti = fmax(ti, fabs(r0)); pl *= sO[j] - qO.L; }
+          auto dist = [&](const Bnd& q, double s_) { if (q.hasL) pl *= s_ - q.L; if (q.hasU) pl *= q.U - s_; };
+          if (bu0_on) dist(qU0, U[0]);
+          if (bu1_on) dist(qU1, U[1]);
+          if (by_on) dist(qY, X[1]);
+          if (bvx_on) dist(qVx, X[3]);
+          if (bvy_on) dist(qVy, X[4]);
+          if (r0_on) dist(qR0, sR0);
+          if (r1_on) dist(qR1, sR1);
+          if (hasu) {      // dyn.py:189-225 with the main phase's constants
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { const double e = X[i] - cst[DCS_XS + i]; fm += cst[DCS_Q + i] * e * e; }
+            fm += cst[DCS_R] * U[0] * U[0] + cst[DCS_R + 1] * U[1] * U[1];
+            if (ducost) {
+              const double d0 = U[0] - (k ? Up0 : cst[DCS_UL]), d1 = U[1] - (k ? Up1 : cst[DCS_UL + 1]);
+              fm += cst[DCS_DR] * d0 * d0 + cst[DCS_DR + 1] * d1 * d1;
+            }
+          }
+          double so[3] = {t1, fm, log(pl)}, mo[1] = {ti};
+          wv::reduce<3, 1>(so, mo);
+          const double th1 = wv::uni(so[0]), thinf = wv::uni(mo[0]);
+          bool leave = false;
+          if (rit >= 1 && th1 <= RS_KAPPA * th_entry && th1 <= tmax_main) {
+            const double phi_o = os * wv::uni(so[1]) - mu_main * wv::uni(so[2]);
+            leave = !(th1 >= fm_theta && phi_o >= fm_phi);
+          }
+          if (!leave && err0 <= c.tol) {
+            if (thinf > c.tol) { status = MPCB_ST_INFEASIBLE; break; }
+            if (rit == 0) { status = MPCB_ST_RESTO_FAILED; break; }
+            leave = true;
+          }
+          if (!leave) {
+            const double V = wv::uni(ss[2]);
+            const double em = fmax(base, fmax(fabs(sv_hi - mu), fabs(sv_lo - mu)) / e_sc);
+            const double gap = (RS_GAP * n_vr * mu + 0.5 * (double)((NX + NU) * N) * sqrt(mu)) / RS_RHO;
+            if (em <= K_EPS * mu && V > gap + 1e-6 && theta <= 0.01 * V) { status = MPCB_ST_INFEASIBLE; break; }
+            if (iters >= c.max_iter) { status = MPCB_ST_MAXITER; break; }
+          } else {
+            // ----- back to the main phase
+            rs = false; osc = os; write_main_cost();
+            double vm = 0;
+            auto vmx = [&](const Bnd& q, const Item& it) { if (q.hasL) vm = fmax(vm, it.vL); if (q.hasU) vm = fmax(vm, it.vU); };
+            if (bu0_on) vmx(qU0, iU0);
+            if (bu1_on) vmx(qU1, iU1);
+            if (by_on) vmx(qY, iY);
+            if (bvx_on) vmx(qVx, iVx);
+            if (bvy_on) vmx(qVy, iVy);
+            if (r0_on) vmx(qR0, iR0);
+            if (r1_on) vmx(qR1, iR1);
+#pragma unroll
+            for (int j = 0; j < NOBS; ++j) { if (ro_on[j]) vm = fmax(vm, vO[j]); }
+#pragma unroll
+            for (int j = 0; j < NEL; ++j) { eP[j] = 0; eN[j] = 0; vP[j] = 0; vN[j] = 0; }
+            if (wv::uni(wv::max(vm)) > 1000.0) {
+              iU0.vL = iU0.vU = iU1.vL = iU1.vU = iY.vL = iY.vU = iVx.vL = iVx.vU = iVy.vL = iVy.vU = iR0.vL = iR0.vU = iR1.vL = iR1.vU = 1.0;
+#pragma unroll
+              for (int j = 0; j < NOBS; ++j) vO[j] = 1.0;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) lam[i] = 0.0;
+            mu = mu_main; tau = fmax(TAU_MIN, 1.0 - mu);
+            theta_max = tmax_main; theta_min = tmin_main;
+            if (lane == 0) { filt[0] = fm_theta; filt[1] = fm_phi; }
+            nfilt = 1;
+            wv::sync();
+            double th, fl, prod;
+            eval_lane(X, U, sR0, sR1, sO, eP, eN, ev, dfc, rR0, rR1, rO, Up0, Up1, th, fl, prod);
+            double sw[3] = {th, fl, log(prod)};
+            wv::reduce<3, 0>(sw, nullptr);
+            theta = wv::uni(sw[0]); fval = wv::uni(sw[1]); logsum = wv::uni(sw[2]);
+            slow_run = 0;
+            continue;
+          }
+        }
+        const double mu_before = mu;
         for (;;) {
-          const double comp = (n_v > 0) ? fmax(fabs(sv_hi - mu), fabs(sv_lo - mu)) : 0.0;
+          const double comp = (n_vr > 0) ? fmax(fabs(sv_hi - mu), fabs(sv_lo - mu)) : 0.0;
           const double em = fmax(base, comp / e_sc);
           if (em <= K_EPS * mu && mu > mu_floor) {
             mu = wv::uni(fmax(mu_floor, fmin(K_MU * mu, mu * sqrt(mu))));
             tau = wv::uni(fmax(TAU_MIN, 1.0 - mu));
             nfilt = 0;
           } else break;
+        }
+        if (RESTO && rs && mu != mu_before) {
+          write_resto_cost(sqrt(mu), false, X, U);
+          double fl = 0;
+          if (xobj) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { const double e = X[i] - cXS(i); fl += cQQ(i) * e * e; }
+          }
+          if (hasu) { const double e0 = U[0] - cUR(0), e1 = U[1] - cUR(1); fl += cRR(0) * e0 * e0 + cRR(1) * e1 * e1; }
+#pragma unroll
+          for (int j = 0; j < NOBS; ++j) if (ro_on[j]) fl += RS_RHO * (eP[j] + eN[j]);
+          fval = wv::uni(wv::sum(fl));
         }
       }
 
@@ -521,15 +786,15 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         double g[NW] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         double h01 = 0, h68 = 0, h79 = 0;
         DynHess Hh = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (xcost) {
+        if (xq) {
 #pragma unroll
-          for (int i = 0; i < NX; ++i) { hd[i] += cst[DCS_WQ + i]; g[i] += cst[DCS_WQ + i] * (X[i] - cst[DCS_XS + i]); }
+          for (int i = 0; i < NX; ++i) { hd[i] += cWQ(i); g[i] += cWQ(i) * (X[i] - cXS(i)); }
         }
         if (hasu) {
-          hd[8] += cst[DCS_WR]; hd[9] += cst[DCS_WR + 1];
-          g[8] += cst[DCS_WR] * U[0]; g[9] += cst[DCS_WR + 1] * U[1];
+          hd[8] += cWR(0); hd[9] += cWR(1);
+          g[8] += cWR(0) * (U[0] - cUR(0)); g[9] += cWR(1) * (U[1] - cUR(1));
           if (ducost) {
-            const double w0 = cst[DCS_WDR], w1 = cst[DCS_WDR + 1];
+            const double w0 = cWDR(0), w1 = cWDR(1);
             const double d0 = U[0] - (k ? Up0 : cst[DCS_UL]), d1 = U[1] - (k ? Up1 : cst[DCS_UL + 1]);
             hd[8] += w0; hd[6] += w0; h68 -= w0; hd[9] += w1; hd[7] += w1; h79 -= w1;
             g[8] += w0 * d0; g[6] -= w0 * d0; g[9] += w1 * d1; g[7] -= w1 * d1;
@@ -547,7 +812,13 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         if (r1_on) { item_sig_gb(iR1, rR1, mu, sig, gb); hd[9] += sig; hd[7] += sig; h79 -= sig; g[9] -= gb; g[7] += gb; }
 #pragma unroll
         for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
-          sig = vO[j] * iO[j]; gb = mu * iO[j] - sig * rO[j];
+          sig = vO[j] * iO[j]; gb = mu * iO[j];
+          if (RESTO && rs) {
+            const double isp = eP[j] / vP[j], isn = eN[j] / vN[j];
+            const double kap = 1.0 / (1.0 + sig * isp + sig * isn);
+            const double rt = rO[j] + (RS_RHO + gb - mu / eP[j]) * isp + (gb - RS_RHO + mu / eN[j]) * isn;
+            sig *= kap; gb -= sig * rt;
+          } else gb -= sig * rO[j];
           hd[0] += sig * gO0[j] * gO0[j] - vO[j] * 2 * ix2[j];
           h01 += sig * gO0[j] * gO1[j];
           hd[1] += sig * gO1[j] * gO1[j] - vO[j] * 2 * iy2[j];
@@ -716,12 +987,26 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         }
       }
       const double dsR0 = r0_on ? (dU[0] - dUp0) + rR0 : 0.0, dsR1 = r1_on ? (dU[1] - dUp1) + rR1 : 0.0;
-      double dsO[NOB];
+      recips();
+      double dsO[NOB], dP[NEL], dN[NEL], dvP[NEL], dvN[NEL];
 #pragma unroll
-      for (int j = 0; j < NOBS; ++j) dsO[j] = ro_on[j] ? gO0[j] * dX[0] + gO1[j] * dX[1] + rO[j] : 0.0;
+      for (int j = 0; j < NEL; ++j) { dP[j] = 0; dN[j] = 0; dvP[j] = 0; dvN[j] = 0; }
+#pragma unroll
+      for (int j = 0; j < NOBS; ++j) {
+        dsO[j] = ro_on[j] ? gO0[j] * dX[0] + gO1[j] * dX[1] + rO[j] : 0.0;
+        if (RESTO && rs && ro_on[j]) {
+          const double sig = vO[j] * iO[j], bs = mu * iO[j];
+          const double sp_ = vP[j] / eP[j], sn_ = vN[j] / eN[j], kap = 1.0 / (1.0 + sig / sp_ + sig / sn_);
+          const double cp_ = (RS_RHO + bs - mu / eP[j]) / sp_, cn_ = (bs - RS_RHO + mu / eN[j]) / sn_;
+          dsO[j] = kap * (dsO[j] + cp_ + cn_);
+          dP[j] = sig * dsO[j] / sp_ - cp_;
+          dN[j] = -sig * dsO[j] / sn_ + cn_;
+          dvP[j] = mu / eP[j] - vP[j] - sp_ * dP[j];
+          dvN[j] = mu / eN[j] - vN[j] - sn_ * dN[j];
+        }
+      }
 
-      recips();                    // (re)computed per phase instead of being kept live across the sweeps: register pressure
-      double a_pr, a_du, dphi;
+      double a_pr, a_du, dphi;     // (the reciprocals were recomputed above instead of being kept live across the sweeps: register pressure)
       {
         double rpr = 0, rdu = 0, d = 0;
         auto ftb = [&](const Bnd& q, const Item& it, double ds) {
@@ -740,16 +1025,20 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
           const double dv = mu * iO[j] - vO[j] - vO[j] * iO[j] * dsO[j];
           rpr = fmax(rpr, -dsO[j] * iO[j]); rdu = fmax(rdu, -dv * wv::rcp(vO[j])); d -= mu * dsO[j] * iO[j];
+          if (RESTO && rs) {
+            rpr = fmax(rpr, fmax(-dP[j] / eP[j], -dN[j] / eN[j])); rdu = fmax(rdu, fmax(-dvP[j] / vP[j], -dvN[j] / vN[j]));
+            d += (RS_RHO - mu / eP[j]) * dP[j] + (RS_RHO - mu / eN[j]) * dN[j];
+          }
         }
-        if (xcost) {
+        if (xq) {
 #pragma unroll
-          for (int i = 0; i < NX; ++i) d += cst[DCS_WQ + i] * (X[i] - cst[DCS_XS + i]) * dX[i];
+          for (int i = 0; i < NX; ++i) d += cWQ(i) * (X[i] - cXS(i)) * dX[i];
         }
         if (hasu) {
-          d += cst[DCS_WR] * U[0] * dU[0] + cst[DCS_WR + 1] * U[1] * dU[1];
+          d += cWR(0) * (U[0] - cUR(0)) * dU[0] + cWR(1) * (U[1] - cUR(1)) * dU[1];
           if (ducost) {
-            d += cst[DCS_WDR] * (U[0] - (k ? Up0 : cst[DCS_UL])) * (dU[0] - (k ? dUp0 : 0.0));
-            d += cst[DCS_WDR + 1] * (U[1] - (k ? Up1 : cst[DCS_UL + 1])) * (dU[1] - (k ? dUp1 : 0.0));
+            d += cWDR(0) * (U[0] - (k ? Up0 : cst[DCS_UL])) * (dU[0] - (k ? dUp0 : 0.0));
+            d += cWDR(1) * (U[1] - (k ? Up1 : cst[DCS_UL + 1])) * (dU[1] - (k ? dUp1 : 0.0));
           }
         }
         double ss[1] = {d}, mm[2] = {rpr, rdu};
@@ -759,7 +1048,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         a_pr = wv::uni((r1 > tau) ? tau / r1 : 1.0);
         a_du = wv::uni((r2 > tau) ? tau / r2 : 1.0);
       }
-      const double phi0 = wv::uni(os * fval - mu * logsum), th0 = theta;
+      const double phi0 = wv::uni(osc * fval - mu * logsum), th0 = theta;
       double a_min;
       if (dphi < 0) {
         a_min = fmin(G_THETA, G_PHI * th0 / (-dphi));
@@ -769,7 +1058,9 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
 
       MPCB_STAMP(t_d);
       double alpha = a_pr; bool accepted = false, armijo_type = false;
-      double Xt[NX], Ut[NU], dft[NX], sR0t, sR1t, rR0t, rR1t, sOt[NOB], rOt[NOB], upt0, upt1, tht = 0, ft = 0, lst = 0;
+      double Xt[NX], Ut[NU], dft[NX], sR0t, sR1t, rR0t, rR1t, sOt[NOB], rOt[NOB], pt[NEL], nt[NEL], upt0, upt1, tht = 0, ft = 0, lst = 0;
+#pragma unroll
+      for (int j = 0; j < NEL; ++j) { pt[j] = 0; nt[j] = 0; }
       DynEval et;
 #pragma clang loop unroll(disable)
       for (;;) {
@@ -779,13 +1070,17 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         sR0t = sR0 + alpha * dsR0; sR1t = sR1 + alpha * dsR1;
 #pragma unroll
         for (int j = 0; j < NOBS; ++j) sOt[j] = sO[j] + alpha * dsO[j];
+        if (RESTO && rs) {
+#pragma unroll
+          for (int j = 0; j < NOBS; ++j) { pt[j] = eP[j] + alpha * dP[j]; nt[j] = eN[j] + alpha * dN[j]; }
+        }
         dyn_eval(c, Xt, Ut, et);
         double th, fl, prod;
-        const bool okl = eval_lane(Xt, Ut, sR0t, sR1t, sOt, et, dft, rR0t, rR1t, rOt, upt0, upt1, th, fl, prod);
+        const bool okl = eval_lane(Xt, Ut, sR0t, sR1t, sOt, pt, nt, et, dft, rR0t, rR1t, rOt, upt0, upt1, th, fl, prod);
         double sv[4] = {th, fl, okl ? log(prod) : 0.0, okl ? 0.0 : 1.0};
         wv::reduce<4, 0>(sv, nullptr);
         tht = wv::uni(sv[0]); ft = wv::uni(sv[1]); lst = wv::uni(sv[2]);
-        const double phit = os * ft - mu * lst;
+        const double phit = osc * ft - mu * lst;
         const bool ok = (wv::uni(sv[3]) == 0.0) && isfinite(tht) && isfinite(phit);
         if (ok && tht <= theta_max) {
           bool fok = true;
@@ -813,7 +1108,22 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         t[4] = (double)(t_b - t_a); t[5] = (double)(t_c - t_b); t[6] = (double)(t_d - t_c); t[7] = (double)(t_e - t_d);
 #endif
       }
-      if (!accepted) { status = MPCB_ST_LINESEARCH; break; }
+      auto hand_over = [&](int it_done) {
+        status = MPCB_ST_NEEDS_RESTO;
+        if (lane == 0 && a.work) {
+          double* wk = a.work + (size_t)b * WK_SIZE;
+          wk[WK_MU] = mu; wk[WK_THMAX] = theta_max; wk[WK_THMIN] = theta_min; wk[WK_ITERS] = (double)it_done; wk[WK_DW] = dw_last;
+        }
+      };
+      if (!accepted) {
+        if (RESTO && rs) { status = MPCB_ST_RESTO_FAILED; break; }
+        if (!c.restoration) { status = MPCB_ST_LINESEARCH; break; }
+        // failure at an (almost) feasible point = round-off in the end game: nothing to restore (IPOPT: "Restoration phase is called
+        // at point that is almost feasible" -> Restoration_Failed); the nearly converged iterate is returned as it is
+        if (e_prim <= c.tol) { status = MPCB_ST_RESTO_FAILED; break; }
+        if (!RESTO) { hand_over(iters); break; }
+        enter = true; continue;
+      }
       if (!armijo_type) {
         if (nfilt < FILTER_MAX) {
           if (lane == 0) { filt[2 * nfilt] = (1 - G_THETA) * th0; filt[2 * nfilt + 1] = phi0 - G_PHI * th0; }
@@ -843,6 +1153,12 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         vO[j] += a_du * dv;
         iO[j] = wv::rcp(sOt[j] - qO.L);
         vO[j] = fmax(fmin(vO[j], K_SIGMA * mu * iO[j]), mu * iO[j] / K_SIGMA);
+        if (RESTO && rs) {
+          eP[j] = pt[j]; eN[j] = nt[j];
+          vP[j] += a_du * dvP[j]; vN[j] += a_du * dvN[j];
+          vP[j] = fmax(fmin(vP[j], K_SIGMA * mu / eP[j]), mu / (K_SIGMA * eP[j]));
+          vN[j] = fmax(fmin(vN[j], K_SIGMA * mu / eN[j]), mu / (K_SIGMA * eN[j]));
+        }
       }
       if (xnode) {
 #pragma unroll
@@ -859,6 +1175,16 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       }
       theta = tht; fval = ft; logsum = lst;
       if (!isfinite(theta) || !isfinite(fval)) { status = MPCB_ST_NUMERIC; break; }
+      ++iters;
+      if (RESTO && rs) ++rit;
+      else if (c.restoration) {       // early entry into restoration (see mpcb_solve_kin)
+        if (alpha < TRIG_ALPHA && theta > 1e-6) { if (slow_run == 0) slow_theta0 = th0; ++slow_run; } else slow_run = 0;
+        if (slow_run >= TRIG_K && theta > TRIG_THETA * slow_theta0) {
+          slow_run = 0;
+          if (!RESTO) { hand_over(iters); break; }
+          enter = true;
+        }
+      }
     }
   } else {
     double Xs[NX];
@@ -867,7 +1193,14 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
     if (!(Xs[3] > 1e-3)) Xs[3] = 1e-3;
     DynEval ev; dyn_eval(c, Xs, U, ev);
     double th, fl, prod;
-    eval_lane(Xs, U, sR0, sR1, sO, ev, dfc, rR0, rR1, rO, Up0, Up1, th, fl, prod);
+    eval_lane(Xs, U, sR0, sR1, sO, eP, eN, ev, dfc, rR0, rR1, rO, Up0, Up1, th, fl, prod);
+    fval = wv::sum(fl);
+  }
+  if (RESTO && rs) {    // ended inside the restoration phase: report the objective of the original problem
+    rs = false; osc = os; write_main_cost();
+    DynEval ev; dyn_eval(c, X, U, ev);
+    double th, fl, prod;
+    eval_lane(X, U, sR0, sR1, sO, eP, eN, ev, dfc, rR0, rR1, rO, Up0, Up1, th, fl, prod);
     fval = wv::sum(fl);
   }
 

@@ -1099,6 +1099,10 @@ struct Solver {
       }
       slow_run = 0;
       if (why != MPCB_ST_LINESEARCH || !c.restoration) { status = why; break; }
+      // a line search that fails at an (almost) feasible point is round-off in the end game, not infeasibility: restoration
+      // has nothing to restore there and would throw the nearly converged multipliers away (IPOPT: "Restoration phase is
+      // called at point that is almost feasible" -> Restoration_Failed).  The iterate is returned as it is.
+      if (why == MPCB_ST_LINESEARCH && e0.prim <= c.tol) { status = MPCB_ST_RESTO_FAILED; break; }
       const int rc = restoration();      // counts its iterations in `iters`
       if (rc != 0) { status = rc; break; }
       --iters;                           // the for-increment belongs to an iteration; the hand-over itself is none

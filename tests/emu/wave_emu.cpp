@@ -20,8 +20,8 @@ template <int NOBS>
 static void run_instance(const MpcbKArgs& a, int b) {
   using namespace mpcbk;
   const bool dyn = a.cfg.model == MPCB_MODEL_DYN;
-  const bool rp = a.pass == 1;                                    // restoration pass: the RESTO instantiations (kin only so far)
-  const int total = dyn ? layout_dyn(a.cfg.N).total : layout_kin(a.cfg.N, a.nz, rp).total;
+  const bool rp = a.pass == 1;                                    // restoration pass: the RESTO instantiations
+  const int total = dyn ? layout_dyn(a.cfg.N, rp).total : layout_kin(a.cfg.N, a.nz, rp).total;
   std::vector<double> lds(total + 64, 0.0);
   std::barrier<> bar(64);
   wv::Emu emu; emu.bar = &bar;
@@ -30,7 +30,8 @@ static void run_instance(const MpcbKArgs& a, int b) {
     th.emplace_back([&, l]() {
       wv::t_lane = l; wv::t_emu = &emu;
       const bool gen = !dyn && a.cfg.obs_mode == MPCB_OBS_DCBF && a.cfg.gamma < 1.0 - 1e-12 && NOBS > 0;   // as mpcb_api.hip dispatches
-      if (dyn) mpcb_solve_dyn<NOBS>(a, b, lds.data());
+      if (dyn && rp) mpcb_solve_dyn<NOBS, true>(a, b, lds.data());
+      else if (dyn) mpcb_solve_dyn<NOBS>(a, b, lds.data());
       else if (gen && rp) mpcb_solve_kin<(NOBS > 0 ? NOBS : 1), true, true>(a, b, lds.data());
       else if (gen) mpcb_solve_kin<(NOBS > 0 ? NOBS : 1), true>(a, b, lds.data());
       else if (rp) mpcb_solve_kin<NOBS, false, true>(a, b, lds.data());
@@ -54,7 +55,7 @@ extern "C" int mpcb_emu_solve(const mpcb_config* cfg, int32_t B, const double* x
   a.x0 = x0; a.xs = xs; a.obs = obs; a.z0 = z0; a.z = z; a.obj = obj; a.kkt = kkt; a.lam_g = lam_g; a.lam_x = lam_x;
   a.status = status; a.iters = iters; a.trace = trace;
   std::vector<double> work((size_t)B * mpcbk::WK_SIZE, 0.0);
-  const bool two_pass = cfg->restoration && cfg->model == MPCB_MODEL_KIN;      // as mpcb_api.hip: first pass, then the restoration pass
+  const bool two_pass = cfg->restoration != 0;                                 // as mpcb_api.hip: first pass, then the restoration pass
   a.work = two_pass ? work.data() : nullptr;
   for (int pass = 0; pass < (two_pass ? 2 : 1); ++pass) {
     a.pass = pass;
