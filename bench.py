@@ -7,14 +7,19 @@
 One "step" = one pass of the solver over one batch per GPU: BASELINE config C2 — kinematic bicycle, N=30, T=0.1 s,
 1 static obstacle [50,3.5,0,8,4.8,1.8], set-point [400,3.5,0,30], batch 4096 random feasible-at-node-0 initial states
 per GPU (seeded), cold start z0 = 0 (as the reference's first step, main_cbf_kin_c_sim.py:47-50).
-Inputs are resident in HBM before the timed region.  Instances are independent, so ranks shard the batch with no
-data-path collective; for N > 1 every step ends with ONE RCCL all-gather of the converged trajectories
-(torch.distributed, backend nccl = RCCL) so that every rank holds all of them — it is inside the timed region.
+Inputs are resident in HBM before the timed region.  Instances are independent, so ranks shard the work with no
+data-path collective; for N > 1 every step ends with ONE RCCL all-gather of the converged trajectories so that every
+rank holds all of them — it is inside the timed region.  RCCL is called by libmpcbatch.so itself (mpcb_comm_init_rank /
+mpcb_allgather / mpcb_allreduce); this file imports no torch: the launcher only provides RANK / WORLD_SIZE / MASTER_*.
 "scaling" is weak: per-GPU batch fixed.
 
 value = instances that reached the KKT tolerance (status 0) on all ranks * K / max-over-ranks wall time.  Instances
-that end with another status (the random scenes include unavoidable collisions, i.e. infeasible NLPs) are counted
-in config.failed_per_step and are NOT part of value, though their time is.
+that end with another status (the random scenes include unavoidable collisions, i.e. locally infeasible NLPs) are
+counted in config.failed_per_step and are NOT part of value, though their time is.
+
+PARITY STATUS: unpinned versus the reference's own solver (CasADi + IPOPT is not installed here or on the GPU box, the
+reference holds no golden outputs): solutions are checked against this repository's CPU oracle and an independent KKT
+certificate, see DESIGN.md §4.
 """
 import argparse
 import json
@@ -29,22 +34,25 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # HIP maps streams onto a small pool of hardware queues (default 4 per process) and two streams on one queue run one
-# after the other; torch + RCCL take several.  More queues keep the solver handles' streams (--inflight) concurrent.
+# after the other; RCCL takes some too.  More queues keep the solver handles' streams (--inflight) concurrent.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (spec)
+PARITY_NOTE = ("parity UNPINNED vs the reference's CasADi+IPOPT (not installed here nor on the GPU box, no golden outputs in the "
+               "reference): results are checked against this repo's CPU oracle (same NLP, IPOPT's published algorithm) and an "
+               "independent KKT certificate (oracle/kkt_check.py)")
 
 
 def measured_traffic(workload):
     """HBM bytes per launch of this workload from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate passes, KiB units,
     2x correction on FETCH_SIZE as MI355X_MICROARCH.md prescribes), recorded by tools/profile_round.sh in profiles/traffic.json.
-    bench.py cannot collect PMC counters on itself, so this is the committed measurement of the same command; None if absent."""
-    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+    A process cannot collect PMC counters on itself, so this is the committed OFFLINE measurement of the same command; None if absent."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         t = json.load(open(p))
-        if t.get("workload") == workload:
-            return float(t["bytes_per_launch"]), "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
+        if t.get("workload_key") == workload.split(":")[0]:
+            return float(t["bytes_per_launch"]), "offline: profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE of this command, committed)"
     except (OSError, ValueError, KeyError):
         pass
     return None, None
@@ -55,17 +63,22 @@ def algorithmic_bytes_per_solve(nx, nz, n_obs_values):
     return 8 * (2 * nx + nz + n_obs_values + nz) + 16
 
 
+def host_cores():
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(1, min(cores, int(os.environ.get("MPCB_CPU_THREADS", "16"))))   # the 1-GPU box's CPU share is 16 cores
+
+
 def cpu_baseline(cfg, x0, xs, obs, min_seconds=1.5):
     """The CPU oracle (oracle/mpc_oracle.cpp, same NLP, same algorithm, OpenMP over the batch) timed on this box's
     host cores on a bounded sample of the same workload.  Reported next to the GPU number; CasADi+IPOPT cannot be
     timed (not installed here nor on the GPU box, no network: SURVEY.md §0 F2)."""
     from oracle import oracle
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("MPCB_CPU_THREADS", "16"))))   # the 1-GPU box's CPU share is 16 cores
+    cores = host_cores()
     n = min(len(x0), 2048)
+    oracle.solve(cfg, x0[:4 * cores], xs[:4 * cores], obs[:4 * cores], threads=cores, want_multipliers=False)   # untimed: starts the OpenMP team, first-touch of the per-thread arenas
     t0 = time.perf_counter(); reps = 0; solved = 0
     while True:
         r = oracle.solve(cfg, x0[:n], xs[:n], obs[:n], threads=cores, want_multipliers=False)
@@ -82,46 +95,138 @@ def cpu_baseline(cfg, x0, xs, obs, min_seconds=1.5):
             "note": "own FP64 C++ restatement of the NLP + IPOPT-style solver; CasADi+IPOPT baseline unavailable (casadi not installed)"}
 
 
-def closed_loop_bench(args, bs, cfg, x0, xs, obs, workload, rank, world):
-    """C5: `steps` = number of complete 80-step closed loops; value counts solved MPC steps per second.  The scenes are split
-    over --inflight solver handles, each running its own closed loop from its own host thread (the steps of one loop depend on
-    each other, independent loops overlap on the GPU like the launches of the other configurations)."""
+def cpu_baseline_closed_loop(cfg, x0, xs, obs, sim_steps, min_seconds=8.0):
+    """C5 on the host: the oracle driving the same receding-horizon loop (solve, plant step, shift, obstacle advance and
+    re-prediction: main_cbf_kin_c_sim_pre.py:86-126) on a bounded sample of the scenes, OpenMP over scenes inside every step."""
+    from oracle import oracle
+    from mpc_motion_planning_amd import scenes
+    cores = host_cores()
+    n = min(len(x0), 256); N = cfg.N
+    xc = x0[:n].copy(); oc = obs[:n].copy(); z0 = np.zeros((n, 2 * N + 4 * (N + 1)))
+    oracle.solve(cfg, xc[:4 * cores], xs[:4 * cores], scenes.predict_obstacles(oc[:4 * cores], cfg.T, N), threads=cores, want_multipliers=False)   # untimed warm-up of the OpenMP team
+    t0 = time.perf_counter(); solved = 0; done = 0
+    for _ in range(sim_steps):
+        r = oracle.solve(cfg, xc, xs[:n], scenes.predict_obstacles(oc, cfg.T, N), z0=z0, threads=cores, want_multipliers=False)
+        solved += int((r["status"] == 0).sum()); done += 1
+        U = r["z"][:, :2 * N].reshape(n, N, 2); X = r["z"][:, 2 * N:].reshape(n, N + 1, 4)
+        f = np.stack([xc[:, 3] * np.cos(xc[:, 2]), xc[:, 3] * np.sin(xc[:, 2]), xc[:, 3] * np.tan(U[:, 0, 0]) / cfg.veh_l, U[:, 0, 1]], axis=1)
+        xc = xc + cfg.T * f
+        z0 = np.concatenate([np.concatenate([U[:, 1:], U[:, -1:]], 1).reshape(n, -1), np.concatenate([X[:, 1:], X[:, -1:]], 1).reshape(n, -1)], 1)
+        oc[:, :, 0] += oc[:, :, 3] * np.cos(oc[:, :, 2]) * cfg.T; oc[:, :, 1] += oc[:, :, 3] * np.sin(oc[:, :, 2]) * cfg.T
+        if time.perf_counter() - t0 >= min_seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": solved / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": "%d scenes x %d of %d closed-loop steps, %.1f s wall (%.0f core-s)" % (n, done, sim_steps, dt, dt * cores),
+            "note": "own FP64 C++ restatement (oracle) driving the same loop; CasADi+IPOPT baseline unavailable (casadi not installed)"}
+
+
+class Group:
+    """The ranks of this run.  world = 1: nothing to do.  world > 1 (or MPCB_BENCH_FORCE_DIST=1, the one-rank rehearsal): a
+    communication handle joins the RCCL group inside libmpcbatch (mpcb_comm_init_rank); the 128-byte group id travels from rank
+    0 to the others over a plain TCP socket on MASTER_PORT + 17."""
+
+    def __init__(self, cfg, rank, world, device, force):
+        from mpc_motion_planning_amd import sharding, solver
+        self.rank, self.world, self.active = rank, world, (world > 1 or force)
+        self.h = None
+        if self.active:
+            self.h = solver.BatchSolver(cfg, device=device)
+            self.h.comm_init(sharding.exchange_unique_id(rank, world, solver.comm_unique_id), rank, world)
+
+    def barrier(self):
+        if self.active:
+            self.h.allreduce([0.0], "sum")
+
+    def reduce(self, values, op):
+        return self.h.allreduce(values, op) if self.active else np.asarray(values, dtype=np.float64)
+
+
+def closed_loop_bench(args, bs, cfg, x0, xs, obs, workload, grp, local_rank):
+    """C5: `steps` // 10 (at least one) complete 80-step closed loops over all scenes; value counts solved MPC steps per second.
+    The scenes are split over a few solver handles, each running its own closed loop from its own host thread (the steps of one
+    loop depend on each other, independent loops overlap on the GPU like the launches of the other configurations)."""
     import threading
     from mpc_motion_planning_amd import _abi
-    from mpc_motion_planning_amd.solver import BatchSolver
+    from mpc_motion_planning_amd.solver import BatchSolver, dims
     sim_steps = 80                                            # sim_time 8 s / T_S 0.1 (main_cbf_kin_c_sim.py:68,87)
-    F = max(1, min(2, args.inflight))                         # measured: 2 loops 879 k, 1 loop 739 k, 3 loops 640 k solved steps/s (host side of 3 loops contends)
-    H = [bs] + [BatchSolver(cfg, device=bs.device) for _ in range(F - 1)]
+    F = max(1, min(int(os.environ.get("MPCB_C5_LOOPS", "4")), args.inflight + 1))
+    H = [bs] + [BatchSolver(cfg, device=local_rank) for _ in range(F - 1)]
     parts = np.array_split(np.arange(len(x0)), F)
     for h_ in H:
         h_.closed_loop(x0[:256], xs[:256], obs[:256], steps=4, obs_motion=_abi.OBSMOVE_PREDICTED)
         h_.timing(reset=True)
     res = [None] * F
 
-    def run(q):
-        res[q] = H[q].closed_loop(x0[parts[q]], xs[parts[q]], obs[parts[q]], steps=sim_steps, obs_motion=_abi.OBSMOVE_PREDICTED)
+    def run(q, hold):
+        res[q] = H[q].closed_loop(x0[parts[q]], xs[parts[q]], obs[parts[q]], steps=sim_steps, obs_motion=_abi.OBSMOVE_PREDICTED,
+                                  hold_on_failure=hold)
 
-    t0 = time.perf_counter()
-    reps = max(1, args.steps // 10)
-    for _ in range(reps):
-        th = [threading.Thread(target=run, args=(q,)) for q in range(F)]
+    def loops(hold):
+        th = [threading.Thread(target=run, args=(q, hold)) for q in range(F)]
         for t_ in th:
             t_.start()
         for t_ in th:
             t_.join()
+        return {k: np.concatenate([r_[k] for r_ in res]) for k in ("status", "iters", "x_hist", "u_hist")}
+
+    grp.barrier()
+    t0 = time.perf_counter()
+    reps = max(1, args.steps // 10)
+    for _ in range(reps):
+        out = loops(False)
+    for h_ in H:
+        h_.sync()
+    grp.barrier()
     dt = time.perf_counter() - t0
     tms = [h_.timing() for h_ in H]
-    status = np.concatenate([r_["status"] for r_ in res]); iters = np.concatenate([r_["iters"] for r_ in res])
+    held = loops(True)                                        # the same scenes once more with the hold-and-shift fallback (untimed)
+    status, iters = out["status"], out["iters"]
+    B = len(x0)
     solved = int((status == 0).sum())
-    out = {"metric": "mpc_solves_per_sec", "value": solved * reps / dt, "unit": "solves/s", "n_gpus": world, "steps": reps, "warmup": args.warmup,
-           "ms_per_step": 1e3 * dt / reps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": workload, "scenes_per_gpu": len(x0), "sim_steps": sim_steps, "solved_steps": solved,
-                      "failed_steps": int(status.size - solved), "scenes_all_steps_solved": int((status == 0).all(axis=1).sum()),
-                      "iters_mean": float(iters.mean()), "host_pointer_entry": True, "loops_in_flight": F,
-                      "kernel_ms_avg": sum(t_["total_ms"] for t_ in tms) / max(1, sum(t_["launches"] for t_ in tms)),
-                      "launches": sum(t_["launches"] for t_ in tms)}}
-    if rank == 0:
-        print(json.dumps(out))
+
+    def min_margin(run_):                                     # smallest obstacle-row value h along the executed trajectories (SURVEY.md 8d)
+        X = run_["x_hist"]
+        t = np.arange(sim_steps + 1)[None, :, None]
+        ox = obs[:, None, :, 0] + obs[:, None, :, 3] * np.cos(obs[:, None, :, 2]) * cfg.T * t
+        oy = obs[:, None, :, 1] + obs[:, None, :, 3] * np.sin(obs[:, None, :, 2]) * cfg.T * t
+        sx = cfg.ego_hl + obs[:, None, :, 4] / 2 + cfg.safe_disl; sy = cfg.ego_hw + obs[:, None, :, 5] / 2 + cfg.safe_disw
+        h = (X[:, :, None, 0] - ox) ** 2 / sx ** 2 + (X[:, :, None, 1] - oy) ** 2 / sy ** 2 - 1.0
+        ok = (run_["status"] == 0).all(axis=1)
+        return (float(h[ok].min()) if ok.any() else None), float(np.nanmin(h)), int(ok.sum()), int((np.nanmin(h, axis=(1, 2)) < -1e-6).sum())
+
+    m_ok, m_all, n_ok, n_coll = min_margin(out)
+    mh_ok, mh_all, nh_ok, nh_coll = min_margin(held)
+    tot = grp.reduce([dt, 0.0], "max"); dt_max = float(tot[0])
+    sums = grp.reduce([float(solved), float(B), float(n_ok)], "sum")
+    nx, nz, ng = dims(cfg)
+    launches = sum(t_["launches"] for t_ in tms)
+    kernel_ms = sum(t_["total_ms"] for t_ in tms) / max(1, launches)
+    per_launch = B // F
+    abytes = algorithmic_bytes_per_solve(nx, nz, int(obs[0].size)) * per_launch      # obstacles predicted on device from [n_obs, 6]
+    res_line = {
+        "metric": "mpc_solves_per_sec", "value": sums[0] * reps / dt_max, "unit": "solves/s", "n_gpus": grp.world, "steps": reps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt_max / reps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": workload, "scenes_per_gpu": B, "sim_steps": sim_steps, "scenes_per_sec": sums[1] * reps / dt_max,
+                   "solved_steps": int(sums[0]), "failed_steps": int(sums[1]) * sim_steps - int(sums[0]),
+                   "failure_rate_steps": 1.0 - sums[0] / (sums[1] * sim_steps),
+                   "status_histogram": {str(k): int(v) for k, v in enumerate(np.bincount(status.ravel(), minlength=7))},
+                   "scenes_all_steps_solved": int(sums[2]), "min_h_scenes_all_solved": m_ok, "min_h_all_scenes": m_all, "scenes_with_collision": n_coll,
+                   "with_hold_on_failure": {"scenes_all_steps_solved": nh_ok, "min_h_scenes_all_solved": mh_ok, "min_h_all_scenes": mh_all,
+                                            "scenes_with_collision": nh_coll, "failed_steps": int((held["status"] != 0).sum())},
+                   "iters_mean": float(iters.mean()), "iters_max": int(iters.max()), "host_pointer_entry": True, "loops_in_flight": F,
+                   "launches": launches, "restoration": bool(cfg.restoration), "collective": "none (scenes are independent for their whole horizon)",
+                   "parity": PARITY_NOTE},
+        "roofline": {"bound": "hbm", "achieved": abytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": abytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "mpcb_kernel_kin<3> + mpcb_kernel_kin_resto<3> (one solve = both passes)", "kernel_ms_avg": kernel_ms,
+                     "algorithmic_bytes_per_launch": abytes,
+                     "note": "compulsory I/O only; the solve is LDS-resident, bound by FP64 VALU issue and the serial Riccati chain (DESIGN.md §5)"},
+    }
+    if grp.rank == 0:
+        if not args.no_cpu_baseline and grp.world == 1:
+            res_line["cpu_baseline"] = cpu_baseline_closed_loop(cfg, x0, xs, obs, sim_steps)
+        print(json.dumps(res_line))
     return 0
 
 
@@ -135,7 +240,8 @@ def main():
                     help="BASELINE.json config: C2 (default, the metric's config) kin+1 static obstacle B=4096; C3 kin+3 predicted "
                          "obstacles B=32768; C4 dyn N=40 3 obstacles B=8192/GPU; C5 closed loop 80 steps (solves = scenes x steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--no-restoration", action="store_true", help="cfg.restoration = 0: a failed line search ends the solve (round-1 behaviour)")
+    ap.add_argument("--inflight", type=int, default=4,
                     help="solver handles (= HIP streams) used round-robin: step k+1 is launched while the tail of step k drains (a launch "
                          "ends with its slowest instance and leaves most SIMDs idle before that); 1 = strictly one launch at a time")
     ap.add_argument("--batches", type=int, default=5,
@@ -152,18 +258,11 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if world == 1 and args.gpus > 1:
-        raise SystemExit("--gpus %d needs the torch.distributed launcher (one process per GPU)" % args.gpus)
+        raise SystemExit("--gpus %d needs one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the "
+                         "environment, e.g. python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d)" % (args.gpus, args.gpus, args.gpus))
 
     from mpc_motion_planning_amd import scenes, _abi
     from mpc_motion_planning_amd.solver import BatchSolver, default_config, dims
-
-    dist = None; torch = None
-    use_dist = world > 1 or os.environ.get("MPCB_BENCH_FORCE_DIST") == "1"    # the env switch rehearses the N > 1 plumbing with one rank
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     conf = args.config
     B = args.batch or {"C2": 4096, "C3": 32768, "C4": 8192, "C5": 4096}[conf]
@@ -192,11 +291,14 @@ def main():
         a0, a1, a2, _ = scenes.sample_c3(B, N=30, dt=0.1, seed=4000 + rank)
         sets.append((a0, a1, a2))
         workload = "C5: closed loop, %d scenes per GPU x 80 receding-horizon steps, kinematic bicycle + 3 moving obstacles re-predicted every step" % B
+    if args.no_restoration:
+        cfg.restoration = 0
     x0, xs, obs = sets[0]
     nx, nz, ng = dims(cfg)
     bs = BatchSolver(cfg, device=local_rank)
+    grp = Group(cfg, rank, world, local_rank, os.environ.get("MPCB_BENCH_FORCE_DIST") == "1")
     if conf == "C5":
-        return closed_loop_bench(args, bs, cfg, x0, xs, obs, workload, rank, world)
+        return closed_loop_bench(args, bs, cfg, x0, xs, obs, workload, grp, local_rank)
     D = []                                                  # per batch: inputs and the status / iteration outputs, all resident in HBM
     for (a0, a1, a2) in sets:
         D.append(dict(x0=bs.device_array((B, nx)).upload(a0), xs=bs.device_array((B, nx)).upload(a1), obs=bs.device_array(a2.shape).upload(a2),
@@ -206,13 +308,8 @@ def main():
     F = max(1, args.inflight)
     H = [bs] + [BatchSolver(cfg, device=local_rank) for _ in range(F - 1)]     # one handle = one stream (include/mpcbatch.h)
     d_obj = [bs.device_array((B,)) for _ in range(F)]; d_kkt = [bs.device_array((B, 4)) for _ in range(F)]
-    if use_dist:    # z lives in torch tensors so that RCCL can gather it; the solver only sees their raw pointers
-        z_bufs = [torch.empty((B, nz), dtype=torch.float64, device="cuda") for _ in range(max(2, F))]
-        z_all = torch.empty((world * B, nz), dtype=torch.float64, device="cuda")
-        z_ptrs = [t.data_ptr() for t in z_bufs]
-        pending = [None] * len(z_bufs); waiting = []        # gathers in flight per z buffer; solves whose gather is not issued yet
-    else:
-        z_ptrs = [bs.device_array((B, nz)) for _ in range(F)]
+    z_bufs = [bs.device_array((B, nz)) for _ in range(F)]
+    z_all = grp.h.device_array((world * B, nz)) if grp.active else None
 
     d_z0 = None
     if args.warm:
@@ -229,39 +326,24 @@ def main():
         d_z0 = bs.device_array((B, nz)).upload(z0)
         workload = workload.replace("cold start z0=0", "cold start").replace("cold start", "WARM start: next receding-horizon step from the shifted previous solution")
 
-    def issue_gathers(keep):
-        # N > 1: a solve whose successor has been launched is waited for (its handle's stream only) and its z is gathered on
-        # RCCL's stream, while the younger solves keep the GPU busy
-        while len(waiting) > keep:
-            hq, zq = waiting.pop(0)
-            H[hq].sync()
-            pending[zq] = dist.all_gather_into_tensor(z_all, z_bufs[zq], async_op=True)
-
     def step(gather=True):
         k = cyc[0]; cyc[0] += 1
         d = D[k % NB]; hq = k % F
-        if not (use_dist and gather):
-            H[hq].solve_device(B, d["x0"], d["xs"], d["obs"], obs_kind, d_z0, z_ptrs[hq], d_obj[hq], d["st"], d["it"], d_kkt[hq])
-            return
-        zq = k % len(z_bufs)
-        if pending[zq] is not None:                     # the gather that last read this buffer must be done
-            pending[zq].wait(); torch.cuda.current_stream().synchronize(); pending[zq] = None
-        H[hq].solve_device(B, d["x0"], d["xs"], d["obs"], obs_kind, d_z0, z_ptrs[zq], d_obj[hq], d["st"], d["it"], d_kkt[hq])
-        waiting.append((hq, zq))
-        issue_gathers(F - 1)
+        if grp.active and gather:
+            H[hq].wait_for(grp.h)                       # the gather that last read this handle's z buffer must be done
+        H[hq].solve_device(B, d["x0"], d["xs"], d["obs"], obs_kind, d_z0, z_bufs[hq], d_obj[hq], d["st"], d["it"], d_kkt[hq])
+        if grp.active and gather:
+            # the all-gather of this step's trajectories runs on the communication handle's stream behind this solve, while the
+            # younger solves of the other handles keep the GPU busy
+            grp.h.wait_for(H[hq])
+            grp.h.allgather(z_bufs[hq], z_all, B * nz)
 
     def fence():
-        if use_dist:
-            issue_gathers(0)
         for h_ in H:
             h_.sync()
-        if use_dist:
-            for w in pending:
-                if w is not None:
-                    w.wait()
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        if grp.active:
+            grp.h.sync()
+        grp.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -274,8 +356,9 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if use_dist and world == 1:       # one-rank rehearsal of the N > 1 plumbing: the gathered block must equal what the last solve wrote
-        assert torch.equal(z_all[:B], z_bufs[(args.steps - 1) % len(z_bufs)]), "all_gather result differs from the solver output"
+    if grp.active:      # the gathered block of this rank must equal what its last solve wrote
+        got = z_all.download()[rank * B:(rank + 1) * B]
+        assert np.array_equal(got, z_bufs[(args.steps - 1) % F].download()), "all-gather result differs from the solver output"
     tms = [h_.timing() for h_ in H]
     tm = {"total_ms": sum(t_["total_ms"] for t_ in tms), "launches": sum(t_["launches"] for t_ in tms)}
 
@@ -286,20 +369,15 @@ def main():
     status = np.concatenate([s_ for u, s_ in zip(uses, st_b) if u]); iters = np.concatenate([i_ for u, i_ in zip(uses, it_b) if u])
     iters_per_launch = sum(u * float(i_.sum()) for u, i_ in zip(uses, it_b)) / max(1, args.steps)
     dt_nogather = None
-    if use_dist:    # the same K steps once more without the gather, reported next to the headline value
+    if grp.active:      # the same K steps once more without the gather, reported next to the headline value
         cyc[0] = 0
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step(gather=False)
         fence()
         dt_nogather = time.perf_counter() - t1
-    if use_dist:
-        t = torch.tensor([dt, float(solved), float(tm["total_ms"]), dt_nogather], dtype=torch.float64, device="cuda")
-        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_max = float(tmax[0]); solved_all = int(round(float(tsum[1]))); dt_nogather = float(tmax[3])
-    else:
-        dt_max = dt; solved_all = solved
+    mx = grp.reduce([dt, dt_nogather or 0.0], "max"); dt_max, dt_nogather_max = float(mx[0]), float(mx[1])
+    solved_all = int(round(float(grp.reduce([float(solved)], "sum")[0])))
 
     if rank == 0:
         kernel_ms = tm["total_ms"] / max(1, tm["launches"])
@@ -308,33 +386,38 @@ def main():
         it_ok = iters[status == 0]
         flops = (147e3 if cfg.model == _abi.MODEL_DYN else 56e3) * iters_per_launch   # ~56 kflop (kin N=30) / ~147 kflop (dyn N=40) per iteration
         traffic, traffic_src = measured_traffic(workload)
+        kk = ("dyn" if cfg.model == _abi.MODEL_DYN else "kin", 1 if cfg.n_obs <= 1 else 3)
+        kname = ("mpcb_kernel_%s<%d>" % kk) + ((" + mpcb_kernel_%s_resto<%d> (one solve = first pass + restoration pass, timed together)" % kk) if cfg.restoration else "")
         out = {
             "metric": "mpc_solves_per_sec", "value": solved_all / dt_max, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "batch_per_gpu": B, "distinct_batches": NB,
                        "solved_per_step": solved_all / args.steps, "failed_per_step": world * B - solved_all / args.steps,
+                       "status_histogram_rank0": {str(k): int(v) for k, v in enumerate(np.bincount(status, minlength=7))},
                        "iters_mean_solved": float(it_ok.mean()) if len(it_ok) else None, "iters_max": int(iters.max()),
-                       "launches_in_flight": F, "tol": cfg.tol, "collective": "rccl all_gather of z per step, overlapped with the next step's solve" if use_dist else "none",
-                       "value_without_gather": (solved_all / dt_nogather) if dt_nogather else None},
+                       "iters_share_of_unsolved": float(iters[status != 0].sum() / max(1, iters.sum())),
+                       "restoration": bool(cfg.restoration),
+                       "launches_in_flight": F, "tol": cfg.tol,
+                       "collective": "RCCL all-gather of z per step inside libmpcbatch (mpcb_allgather), overlapped with the next steps' solves" if grp.active else "none",
+                       "value_without_gather": (solved_all / dt_nogather_max) if dt_nogather else None,
+                       "multi_gpu_note": "no N > 1 number has been measured on hardware by the builder (one-GPU boxes only); the driver's SCALE run is the measurement",
+                       "parity": PARITY_NOTE},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "mpcb_kernel_%s<%d>" % ("dyn" if cfg.model == _abi.MODEL_DYN else "kin", 1 if cfg.n_obs <= 1 else 3), "kernel_ms_avg": kernel_ms,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": kname, "kernel_ms_avg": kernel_ms,
                          "algorithmic_bytes_per_launch": abytes,
                          "achieved_over_wall_clock": abytes * args.steps / dt_max / 1e9,   # launches overlap (launches_in_flight): each one lasts longer than a step
-
                          "note": "compulsory I/O is 3072 B/solve; the solve is LDS-resident, bound by FP64 VALU issue and the serial "
                                  "Riccati chain, not by HBM (SURVEY.md F10, DESIGN.md §5)"},
             "roofline_fp64": {"bound": "fp64_valu", "achieved": flops * args.steps / dt_max / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": flops * args.steps / dt_max / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                              "model": "56 kflop x interior-point iterations summed over the batch, per step, over the wall clock of the "
-                                       "timed region (launches overlap, so a launch lasts longer than a step)"},
+                              "model": "56 kflop (kin) / 147 kflop (dyn) x interior-point iterations summed over the batch, per step, over the "
+                                       "wall clock of the timed region (launches overlap, so a launch lasts longer than a step)"},
         }
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, x0, xs, obs)
         print(json.dumps(out))
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.barrier()
 
 
 if __name__ == "__main__":

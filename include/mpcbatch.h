@@ -196,12 +196,40 @@ int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps,
                      const double* x0, const double* xs, double* obs_state, int32_t obs_motion, int32_t flags,
                      double* x_hist, double* u_hist, int32_t* status_hist, int32_t* iters_hist);
 
+/* ---- multi-GPU ---------------------------------------------------------------------------------------------
+ * Instances are independent NLPs (every `solver(...)` call of main_cbf_kin_c_sim.py:100 stands alone), so a batch is cut into
+ * contiguous shards, one per GPU, with NO data-path collective; one RCCL all-gather of the converged trajectories over xGMI
+ * afterwards gives every GPU all of them.  RCCL is called from inside this library (librccl is loaded on first use); no
+ * torch.distributed, no MPI.  Two ways to form the group:
+ *   (a) one process per GPU (the launch bench.py is given: RANK / WORLD_SIZE / MASTER_* in the environment):
+ *       rank 0 calls mpcb_comm_unique_id, the 128 bytes travel to the other ranks over any host channel, every rank calls
+ *       mpcb_comm_init_rank on its handle (ncclCommInitRank).  mpcb_allgather / mpcb_allreduce then work on that handle.
+ *   (b) one process driving n devices: mpcb_set_devices(h, ids, n) (ncclCommInitAll).  mpcb_solve on that handle cuts the
+ *       host batch into n contiguous shards, solves them concurrently, all-gathers z so that every device holds all of it
+ *       (mpcb_gathered_z), and returns the whole batch to the caller. */
+#define MPCB_UNIQUE_ID_BYTES 128
+/* contiguous shard [lo, hi) of `rank` among `world`: sizes differ by at most one, earlier ranks take the remainder (host only) */
+int mpcb_shard_bounds(int64_t B, int32_t world, int32_t rank, int64_t* lo, int64_t* hi);
+int mpcb_comm_unique_id(void* id128);
+int mpcb_comm_init_rank(mpcb_handle* h, const void* id128, int32_t rank, int32_t world);
+int mpcb_set_devices(mpcb_handle* h, const int32_t* device_ids, int32_t n);
+int mpcb_comm_info(const mpcb_handle* h, int32_t* world, int32_t* rank);       /* world = 1 before any of the two calls above */
+/* d_recv [world, count] <- every rank's d_send [count] (doubles, device pointers), asynchronous on the handle's stream */
+int mpcb_allgather(mpcb_handle* h, const double* d_send, double* d_recv, uint64_t count);
+/* in-place reduction of n host doubles over the ranks, op 0 = sum, 1 = max; synchronises the handle's stream (a barrier) */
+int mpcb_allreduce(mpcb_handle* h, double* values, int32_t n, int32_t op);
+/* (b) only: device pointer of the [B, nz] trajectories of the last mpcb_solve as gathered on device `index` of the group */
+int mpcb_gathered_z(mpcb_handle* h, int32_t index, const double** d_z);
+
 /* device memory helpers so that Python (ctypes, no torch) can keep batches resident */
 int mpcb_dev_alloc(mpcb_handle* h, uint64_t bytes, void** dptr);
 int mpcb_dev_free(mpcb_handle* h, void* dptr);
 int mpcb_dev_upload(mpcb_handle* h, void* dptr, const void* src, uint64_t bytes);
 int mpcb_dev_download(mpcb_handle* h, void* dst, const void* dptr, uint64_t bytes);
 int mpcb_sync(mpcb_handle* h);
+/* h's stream waits (on the device, the host does not block) for everything queued so far on other's stream: lets work of
+ * several handles be chained, e.g. an all-gather on a communication handle behind the solve of a solver handle */
+int mpcb_stream_wait(mpcb_handle* h, mpcb_handle* other);
 
 /* HIP-event timing of the solve kernel on the handle's stream since the last reset:
  * number of launches, total and last kernel milliseconds. */

@@ -19,6 +19,7 @@ INT_EULER, INT_RK4 = 0, 1
 CL_HOLD_ON_FAILURE, CL_ADVANCE_FIRST_ONLY = 1, 2
 OBSMOVE_STATIC, OBSMOVE_PREDICTED, OBSMOVE_CURRENT = 0, 1, 2
 NX_MAX, NU, NOBS_MAX, N_MAX = 6, 2, 8, 63
+UNIQUE_ID_BYTES = 128
 
 _d = C.c_double
 _i = C.c_int32

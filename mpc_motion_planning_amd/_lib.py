@@ -29,11 +29,20 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "mpcb_solve_trace": (C.c_int, [_H, _PD, _PD, _PD, C.c_int32, _PD, _PD, _PI, _PI, _PD]),
     "mpcb_closed_loop": (C.c_int, [_H, C.c_int32, C.c_int32, _PD, _PD, _PD, C.c_int32, C.c_int32, _PD, _PD, _PI, _PI]),
+    "mpcb_shard_bounds": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "mpcb_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "mpcb_comm_init_rank": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32]),
+    "mpcb_set_devices": (C.c_int, [_H, _PI, C.c_int32]),
+    "mpcb_comm_info": (C.c_int, [_H, _PI, _PI]),
+    "mpcb_allgather": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "mpcb_allreduce": (C.c_int, [_H, _PD, C.c_int32, C.c_int32]),
+    "mpcb_gathered_z": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_void_p)]),
     "mpcb_dev_alloc": (C.c_int, [_H, C.c_uint64, C.POINTER(C.c_void_p)]),
     "mpcb_dev_free": (C.c_int, [_H, C.c_void_p]),
     "mpcb_dev_upload": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_uint64]),
     "mpcb_dev_download": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_uint64]),
     "mpcb_sync": (C.c_int, [_H]),
+    "mpcb_stream_wait": (C.c_int, [_H, _H]),
     "mpcb_timing": (C.c_int, [_H, C.c_int32, _PI, _PD, _PD]),
     "mpcb_model_rhs": (C.c_int, [C.POINTER(MpcbConfig), _PD, _PD, _PD]),
 }

@@ -3,6 +3,8 @@
 // Host side: plain HIP runtime, one stream per handle, caller-owned buffers.  No torch, no oracle, no CPU
 // fallback: without a HIP device mpcb_create fails with MPCB_E_DEVICE.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>     // types and prototypes only: librccl is loaded on first use (dlopen), see Rccl below
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -159,6 +161,15 @@ struct mpcb_handle {
   // two-pass solve (cfg.restoration): hand-over records [B][WK_SIZE] and, when the caller passes no status array, the status
   // column the passes communicate through
   double* d_work = nullptr; int32_t* d_st_own = nullptr; int work_cap = 0;
+  // multi-GPU: (a) this handle is rank `rank` of `world` processes (mpcb_comm_init_rank), or (b) it leads a group of
+  // `peers.size()` devices of this process (mpcb_set_devices; peers[0] is a sibling handle on the leader's own device)
+  ncclComm_t comm = nullptr; int world = 1, rank = 0;
+  std::vector<mpcb_handle*> peers;
+  double* d_gather = nullptr; size_t gather_cap = 0;   // (b): [world, longest shard, nz] all-gather target on this device
+  double* d_red = nullptr;                             // small device buffer for mpcb_allreduce
+  hipEvent_t ev_sync = nullptr;                        // mpcb_stream_wait: marks "everything queued so far on this stream"
+  size_t gathered_rows = 0;                            // (b): rows per shard block of the last gather, B of that solve
+  int64_t gathered_B = 0;
 };
 
 namespace {
@@ -171,6 +182,33 @@ int fail(mpcb_handle* h, int code, const char* fmt, ...) {
 }
 #define HIP_TRY(h, expr)                                                                         \
   do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(h, MPCB_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+// librccl, loaded on first use so that a process that never forms a group does not pay for (or depend on) it
+struct Rccl {
+  decltype(&ncclGetUniqueId) GetUniqueId; decltype(&ncclCommInitRank) CommInitRank; decltype(&ncclCommInitAll) CommInitAll;
+  decltype(&ncclCommDestroy) CommDestroy; decltype(&ncclAllGather) AllGather; decltype(&ncclAllReduce) AllReduce;
+  decltype(&ncclGroupStart) GroupStart; decltype(&ncclGroupEnd) GroupEnd; decltype(&ncclGetErrorString) GetErrorString;
+};
+std::string g_rccl_error;
+const Rccl* rccl() {
+  static Rccl R; static int state = 0;                       // 0 untried, 1 loaded, -1 failed
+  if (state == 0) {
+    void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!so) so = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!so) { g_rccl_error = dlerror() ? dlerror() : "dlopen failed"; state = -1; return nullptr; }
+    bool ok = true;
+#define MPCB_SYM(field, name) do { R.field = (decltype(R.field))dlsym(so, name); if (!R.field) { ok = false; g_rccl_error = std::string("missing symbol ") + name; } } while (0)
+    MPCB_SYM(GetUniqueId, "ncclGetUniqueId"); MPCB_SYM(CommInitRank, "ncclCommInitRank"); MPCB_SYM(CommInitAll, "ncclCommInitAll");
+    MPCB_SYM(CommDestroy, "ncclCommDestroy"); MPCB_SYM(AllGather, "ncclAllGather"); MPCB_SYM(AllReduce, "ncclAllReduce");
+    MPCB_SYM(GroupStart, "ncclGroupStart"); MPCB_SYM(GroupEnd, "ncclGroupEnd"); MPCB_SYM(GetErrorString, "ncclGetErrorString");
+#undef MPCB_SYM
+    state = ok ? 1 : -1;
+  }
+  return state == 1 ? &R : nullptr;
+}
+#define NCCL_TRY(h, R, expr)                                                                     \
+  do { ncclResult_t e_ = (expr); if (e_ != ncclSuccess) return fail(h, MPCB_E_DEVICE, "%s: %s", #expr, (R)->GetErrorString(e_)); } while (0)
 
 int nx_of(const mpcb_config& c) { return c.model == MPCB_MODEL_DYN ? 6 : 4; }
 int n_rate(const mpcb_config& c) {
@@ -440,6 +478,11 @@ int mpcb_destroy(mpcb_handle* h) {
   collect_timing(h);
   for (auto& p : h->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   if (h->d_buf) (void)hipFree(h->d_buf);
+  for (auto* p : h->peers) mpcb_destroy(p);
+  if (h->comm) { const Rccl* R = rccl(); if (R) (void)R->CommDestroy(h->comm); }
+  if (h->d_gather) (void)hipFree(h->d_gather);
+  if (h->d_red) (void)hipFree(h->d_red);
+  if (h->ev_sync) (void)hipEventDestroy(h->ev_sync);
   if (h->d_work) (void)hipFree(h->d_work);
   if (h->d_st_own) (void)hipFree(h->d_st_own);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -519,47 +562,136 @@ int mpcb_solve_device(mpcb_handle* h, int32_t B, const double* d_x0, const doubl
   return MPCB_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// One host-pointer solve on one device, in two halves so that a device group can issue every shard before it waits for any:
+// issue() uploads the inputs and launches the solve (asynchronous on the handle's stream), collect() queues the downloads.
+struct HostSolve {
+  mpcb_handle* h; int32_t B; int obs_kind;
+  const double *x0, *xs, *obs, *z0; double *z, *obj, *kkt, *lam_g, *lam_x; int32_t *status, *iters;
+  double *d_x0, *d_xs, *d_obs, *d_z0, *d_z, *d_obj, *d_kkt, *d_lg, *d_lx; int32_t *d_st, *d_it;
+  int issue() {
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int nx = h->nx, nz = h->nz, ng = h->ng, N = h->cfg.N;
+    const size_t n_obs_d = (size_t)B * h->cfg.n_obs * 6 * (obs_kind == MPCB_OBSIN_PREDICTED ? N + 1 : 1);
+    auto carve = [&](Carve& cv) {
+      d_x0 = cv.take<double>((size_t)B * nx);
+      d_xs = cv.take<double>((size_t)B * nx);
+      d_obs = n_obs_d ? cv.take<double>(n_obs_d) : nullptr;
+      d_z0 = z0 ? cv.take<double>((size_t)B * nz) : nullptr;
+      d_z = cv.take<double>((size_t)B * nz);
+      d_obj = cv.take<double>(B);
+      d_kkt = cv.take<double>((size_t)B * 4);
+      d_lg = lam_g ? cv.take<double>((size_t)B * ng) : nullptr;
+      d_lx = lam_x ? cv.take<double>((size_t)B * nz) : nullptr;
+      d_st = cv.take<int32_t>(B);
+      d_it = cv.take<int32_t>(B);
+    };
+    { Carve dry{nullptr}; carve(dry); int rc = ensure_scratch(h, dry.bytes()); if (rc != MPCB_OK) return rc; }
+    { Carve cv{(char*)h->d_buf}; carve(cv); }
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(d_x0, x0, (size_t)B * nx * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_xs, xs, (size_t)B * nx * 8, hipMemcpyHostToDevice, s));
+    if (d_obs) HIP_TRY(h, hipMemcpyAsync(d_obs, obs, n_obs_d * 8, hipMemcpyHostToDevice, s));
+    if (d_z0) HIP_TRY(h, hipMemcpyAsync(d_z0, z0, (size_t)B * nz * 8, hipMemcpyHostToDevice, s));
+    return solve_on_device(h, B, d_x0, d_xs, d_obs, obs_kind, d_z0, d_z, d_obj, d_st, d_it, 1, d_kkt, d_lg, d_lx);
+  }
+  int collect() {
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int nz = h->nz, ng = h->ng;
+    hipStream_t s = h->stream;
+    if (z) HIP_TRY(h, hipMemcpyAsync(z, d_z, (size_t)B * nz * 8, hipMemcpyDeviceToHost, s));
+    if (obj) HIP_TRY(h, hipMemcpyAsync(obj, d_obj, (size_t)B * 8, hipMemcpyDeviceToHost, s));
+    if (kkt) HIP_TRY(h, hipMemcpyAsync(kkt, d_kkt, (size_t)B * 4 * 8, hipMemcpyDeviceToHost, s));
+    if (status) HIP_TRY(h, hipMemcpyAsync(status, d_st, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    if (iters) HIP_TRY(h, hipMemcpyAsync(iters, d_it, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    if (lam_g) HIP_TRY(h, hipMemcpyAsync(lam_g, d_lg, (size_t)B * ng * 8, hipMemcpyDeviceToHost, s));
+    if (lam_x) HIP_TRY(h, hipMemcpyAsync(lam_x, d_lx, (size_t)B * nz * 8, hipMemcpyDeviceToHost, s));
+    return MPCB_OK;
+  }
+};
+
+// mpcb_solve on a device group (mpcb_set_devices): contiguous shards, no data-path collective, one all-gather of z
+int solve_group(mpcb_handle* h, int32_t B, const double* x0, const double* xs, const double* obs, int32_t obs_kind, const double* z0,
+                double* z, double* obj, int32_t* status, int32_t* iters, double* kkt, double* lam_g, double* lam_x) {
+  const int G = (int)h->peers.size(), nx = h->nx, nz = h->nz, ng = h->ng, N = h->cfg.N;
+  const size_t obs_row = (size_t)h->cfg.n_obs * 6 * (obs_kind == MPCB_OBSIN_PREDICTED ? N + 1 : 1);
+  const Rccl* R = rccl();
+  std::vector<HostSolve> part(G);
+  int64_t longest = 0;
+  for (int g = 0; g < G; ++g) { int64_t lo, hi; mpcb_shard_bounds(B, G, g, &lo, &hi); if (hi - lo > longest) longest = hi - lo; }
+  for (int g = 0; g < G; ++g) {
+    int64_t lo, hi; mpcb_shard_bounds(B, G, g, &lo, &hi);
+    mpcb_handle* p = h->peers[g];
+    p->cfg = h->cfg;                                       // (bounds adopted by mpcb_set_bounds on the leader)
+    HostSolve& q = part[g];
+    q = HostSolve{};
+    q.h = p; q.B = (int32_t)(hi - lo); q.obs_kind = obs_kind;
+    q.x0 = x0 + lo * nx; q.xs = xs + lo * nx; q.obs = obs ? obs + lo * obs_row : nullptr; q.z0 = z0 ? z0 + lo * nz : nullptr;
+    q.z = nullptr;                                         // z comes back from the gathered copy
+    q.obj = obj ? obj + lo : nullptr; q.kkt = kkt ? kkt + lo * 4 : nullptr; q.status = status ? status + lo : nullptr;
+    q.iters = iters ? iters + lo : nullptr; q.lam_g = lam_g ? lam_g + lo * ng : nullptr; q.lam_x = lam_x ? lam_x + lo * nz : nullptr;
+    // all-gather target and a padded send block (shards may differ by one row) on this device
+    HIP_TRY(p, hipSetDevice(p->device));
+    const size_t need = (size_t)(G + 1) * longest * nz;
+    if (need > p->gather_cap) {
+      if (p->d_gather) HIP_TRY(p, hipFree(p->d_gather));
+      p->d_gather = nullptr; p->gather_cap = 0;
+      HIP_TRY(p, hipMalloc(&p->d_gather, need * sizeof(double)));
+      p->gather_cap = need;
+    }
+    if (q.B > 0) { int rc = q.issue(); if (rc != MPCB_OK) return fail(h, rc, "device %d: %s", p->device, p->err.c_str()); }
+    double* send = p->d_gather + (size_t)G * longest * nz;
+    if (q.B < longest) HIP_TRY(p, hipMemsetAsync(send, 0, (size_t)longest * nz * 8, p->stream));
+    if (q.B > 0) HIP_TRY(p, hipMemcpyAsync(send, q.d_z, (size_t)q.B * nz * 8, hipMemcpyDeviceToDevice, p->stream));
+  }
+  // one all-gather over xGMI: every device ends up with every shard's trajectories
+  NCCL_TRY(h, R, R->GroupStart());
+  for (int g = 0; g < G; ++g) {
+    mpcb_handle* p = h->peers[g];
+    ncclResult_t e = R->AllGather(p->d_gather + (size_t)G * longest * nz, p->d_gather, (size_t)longest * nz, ncclDouble, p->comm, p->stream);
+    if (e != ncclSuccess) { (void)R->GroupEnd(); return fail(h, MPCB_E_DEVICE, "ncclAllGather: %s", R->GetErrorString(e)); }
+  }
+  NCCL_TRY(h, R, R->GroupEnd());
+  for (int g = 0; g < G; ++g) {
+    mpcb_handle* p = h->peers[g];
+    if (part[g].B > 0) { int rc = part[g].collect(); if (rc != MPCB_OK) return fail(h, rc, "device %d: %s", p->device, p->err.c_str()); }
+    p->gathered_rows = (size_t)longest; p->gathered_B = B;
+  }
+  // the caller's z: the gathered copy of device 0, shard blocks de-padded
+  mpcb_handle* p0 = h->peers[0];
+  HIP_TRY(p0, hipSetDevice(p0->device));
+  for (int g = 0; g < G; ++g) {
+    int64_t lo, hi; mpcb_shard_bounds(B, G, g, &lo, &hi);
+    if (hi > lo) HIP_TRY(p0, hipMemcpyAsync(z + lo * nz, p0->d_gather + (size_t)g * longest * nz, (size_t)(hi - lo) * nz * 8, hipMemcpyDeviceToHost, p0->stream));
+  }
+  for (int g = 0; g < G; ++g) { mpcb_handle* p = h->peers[g]; HIP_TRY(p, hipSetDevice(p->device)); HIP_TRY(p, hipStreamSynchronize(p->stream)); }
+  HIP_TRY(h, hipSetDevice(h->device));
+  return MPCB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int mpcb_solve(mpcb_handle* h, int32_t B, const double* x0, const double* xs, const double* obs, int32_t obs_kind, const double* z0,
                double* z, double* obj, int32_t* status, int32_t* iters, double* kkt, double* lam_g, double* lam_x) {
   if (!h) return MPCB_E_INVALID;
   if (B < 0 || !x0 || !xs || !z) return fail(h, MPCB_E_INVALID, "B < 0 or a required pointer is NULL");
   if (h->cfg.n_obs > 0 && !obs) return fail(h, MPCB_E_INVALID, "n_obs = %d but obs is NULL", h->cfg.n_obs);
+  if (obs_kind != MPCB_OBSIN_STATIC && obs_kind != MPCB_OBSIN_PREDICTED) return fail(h, MPCB_E_INVALID, "unknown obs_kind %d", obs_kind);
   if (B == 0) return MPCB_OK;
-  HIP_TRY(h, hipSetDevice(h->device));
-  const int nx = h->nx, nz = h->nz, ng = h->ng, N = h->cfg.N;
-  const size_t n_obs_d = (size_t)B * h->cfg.n_obs * 6 * (obs_kind == MPCB_OBSIN_PREDICTED ? N + 1 : 1);
-  double *d_x0, *d_xs, *d_obs, *d_z0, *d_z, *d_obj, *d_kkt, *d_lg, *d_lx; int32_t *d_st, *d_it;
-  auto carve = [&](Carve& cv) {
-    d_x0 = cv.take<double>((size_t)B * nx);
-    d_xs = cv.take<double>((size_t)B * nx);
-    d_obs = n_obs_d ? cv.take<double>(n_obs_d) : nullptr;
-    d_z0 = z0 ? cv.take<double>((size_t)B * nz) : nullptr;
-    d_z = cv.take<double>((size_t)B * nz);
-    d_obj = cv.take<double>(B);
-    d_kkt = cv.take<double>((size_t)B * 4);
-    d_lg = lam_g ? cv.take<double>((size_t)B * ng) : nullptr;
-    d_lx = lam_x ? cv.take<double>((size_t)B * nz) : nullptr;
-    d_st = cv.take<int32_t>(B);
-    d_it = cv.take<int32_t>(B);
-  };
-  { Carve dry{nullptr}; carve(dry); int rc = ensure_scratch(h, dry.bytes()); if (rc != MPCB_OK) return rc; }
-  { Carve cv{(char*)h->d_buf}; carve(cv); }
-  int rc = MPCB_OK;
-  hipStream_t s = h->stream;
-  HIP_TRY(h, hipMemcpyAsync(d_x0, x0, (size_t)B * nx * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(h, hipMemcpyAsync(d_xs, xs, (size_t)B * nx * 8, hipMemcpyHostToDevice, s));
-  if (d_obs) HIP_TRY(h, hipMemcpyAsync(d_obs, obs, n_obs_d * 8, hipMemcpyHostToDevice, s));
-  if (d_z0) HIP_TRY(h, hipMemcpyAsync(d_z0, z0, (size_t)B * nz * 8, hipMemcpyHostToDevice, s));
-  rc = mpcb_solve_device(h, B, d_x0, d_xs, d_obs, obs_kind, d_z0, d_z, d_obj, d_st, d_it, d_kkt, d_lg, d_lx, 0);
+  if (!h->peers.empty()) return solve_group(h, B, x0, xs, obs, obs_kind, z0, z, obj, status, iters, kkt, lam_g, lam_x);
+  HostSolve q{};
+  q.h = h; q.B = B; q.obs_kind = obs_kind; q.x0 = x0; q.xs = xs; q.obs = obs; q.z0 = z0;
+  q.z = z; q.obj = obj; q.kkt = kkt; q.lam_g = lam_g; q.lam_x = lam_x; q.status = status; q.iters = iters;
+  int rc = q.issue();
   if (rc != MPCB_OK) return rc;
-  HIP_TRY(h, hipMemcpyAsync(z, d_z, (size_t)B * nz * 8, hipMemcpyDeviceToHost, s));
-  if (obj) HIP_TRY(h, hipMemcpyAsync(obj, d_obj, (size_t)B * 8, hipMemcpyDeviceToHost, s));
-  if (kkt) HIP_TRY(h, hipMemcpyAsync(kkt, d_kkt, (size_t)B * 4 * 8, hipMemcpyDeviceToHost, s));
-  if (status) HIP_TRY(h, hipMemcpyAsync(status, d_st, (size_t)B * 4, hipMemcpyDeviceToHost, s));
-  if (iters) HIP_TRY(h, hipMemcpyAsync(iters, d_it, (size_t)B * 4, hipMemcpyDeviceToHost, s));
-  if (lam_g) HIP_TRY(h, hipMemcpyAsync(lam_g, d_lg, (size_t)B * ng * 8, hipMemcpyDeviceToHost, s));
-  if (lam_x) HIP_TRY(h, hipMemcpyAsync(lam_x, d_lx, (size_t)B * nz * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(h, hipStreamSynchronize(s));
+  rc = q.collect();
+  if (rc != MPCB_OK) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MPCB_OK;
 }
 
@@ -664,6 +796,103 @@ int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps, const double* x0,
   return MPCB_OK;
 }
 
+// ---- multi-GPU ----------------------------------------------------------------------------------------------------------
+int mpcb_shard_bounds(int64_t B, int32_t world, int32_t rank, int64_t* lo, int64_t* hi) {
+  if (B < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi) return MPCB_E_INVALID;
+  const int64_t q = B / world, r = B % world;
+  *lo = rank * q + (rank < r ? rank : r);
+  *hi = *lo + q + (rank < r ? 1 : 0);
+  return MPCB_OK;
+}
+
+int mpcb_comm_unique_id(void* id128) {
+  if (!id128) return MPCB_E_INVALID;
+  const Rccl* R = rccl();
+  if (!R) return fail(nullptr, MPCB_E_DEVICE, "librccl.so could not be loaded: %s", g_rccl_error.c_str());
+  static_assert(sizeof(ncclUniqueId) == MPCB_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  ncclResult_t e = R->GetUniqueId(&id);
+  if (e != ncclSuccess) return fail(nullptr, MPCB_E_DEVICE, "ncclGetUniqueId: %s", R->GetErrorString(e));
+  std::memcpy(id128, &id, sizeof id);
+  return MPCB_OK;
+}
+
+int mpcb_comm_init_rank(mpcb_handle* h, const void* id128, int32_t rank, int32_t world) {
+  if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return fail(h, MPCB_E_INVALID, "bad rank / world");
+  if (h->comm || !h->peers.empty()) return fail(h, MPCB_E_INVALID, "the handle already belongs to a group");
+  const Rccl* R = rccl();
+  if (!R) return fail(h, MPCB_E_DEVICE, "librccl.so could not be loaded: %s", g_rccl_error.c_str());
+  HIP_TRY(h, hipSetDevice(h->device));
+  ncclUniqueId id; std::memcpy(&id, id128, sizeof id);
+  NCCL_TRY(h, R, R->CommInitRank(&h->comm, world, id, rank));
+  h->world = world; h->rank = rank;
+  HIP_TRY(h, hipMalloc(&h->d_red, 64 * sizeof(double)));
+  return MPCB_OK;
+}
+
+int mpcb_set_devices(mpcb_handle* h, const int32_t* ids, int32_t n) {
+  if (!h || !ids || n < 1) return fail(h, MPCB_E_INVALID, "bad device list");
+  if (h->comm || !h->peers.empty()) return fail(h, MPCB_E_INVALID, "the handle already belongs to a group");
+  int ndev = 0;
+  HIP_TRY(h, hipGetDeviceCount(&ndev));
+  for (int i = 0; i < n; ++i) {
+    if (ids[i] < 0 || ids[i] >= ndev) return fail(h, MPCB_E_INVALID, "device %d outside 0..%d", ids[i], ndev - 1);
+    for (int j = 0; j < i; ++j) if (ids[j] == ids[i]) return fail(h, MPCB_E_INVALID, "device %d listed twice", ids[i]);
+  }
+  const Rccl* R = rccl();
+  if (!R) return fail(h, MPCB_E_DEVICE, "librccl.so could not be loaded: %s", g_rccl_error.c_str());
+  std::vector<mpcb_handle*> peers(n, nullptr);
+  for (int i = 0; i < n; ++i) {
+    int rc = mpcb_create(&h->cfg, ids[i], &peers[i]);
+    if (rc != MPCB_OK) { for (auto* p : peers) mpcb_destroy(p); return fail(h, rc, "device %d: %s", ids[i], g_create_error.c_str()); }
+  }
+  std::vector<ncclComm_t> comms(n);
+  std::vector<int> devs(ids, ids + n);
+  ncclResult_t e = R->CommInitAll(comms.data(), n, devs.data());
+  if (e != ncclSuccess) { for (auto* p : peers) mpcb_destroy(p); return fail(h, MPCB_E_DEVICE, "ncclCommInitAll: %s", R->GetErrorString(e)); }
+  for (int i = 0; i < n; ++i) { peers[i]->comm = comms[i]; peers[i]->world = n; peers[i]->rank = i; }
+  h->peers = peers; h->world = n; h->rank = 0;
+  return MPCB_OK;
+}
+
+int mpcb_comm_info(const mpcb_handle* h, int32_t* world, int32_t* rank) {
+  if (!h) return MPCB_E_INVALID;
+  if (world) *world = h->world;
+  if (rank) *rank = h->rank;
+  return MPCB_OK;
+}
+
+int mpcb_allgather(mpcb_handle* h, const double* d_send, double* d_recv, uint64_t count) {
+  if (!h || !d_send || !d_recv) return fail(h, MPCB_E_INVALID, "NULL argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (h->world == 1 && !h->comm) {               // no group: the gather of one block is a copy
+    if (d_recv != d_send) HIP_TRY(h, hipMemcpyAsync(d_recv, d_send, count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return MPCB_OK;
+  }
+  if (!h->comm) return fail(h, MPCB_E_INVALID, "mpcb_allgather on a group leader: use mpcb_solve, which gathers");
+  const Rccl* R = rccl();
+  NCCL_TRY(h, R, R->AllGather(d_send, d_recv, count, ncclDouble, h->comm, h->stream));
+  return MPCB_OK;
+}
+
+int mpcb_allreduce(mpcb_handle* h, double* values, int32_t n, int32_t op) {
+  if (!h || !values || n < 1 || n > 64 || (op != 0 && op != 1)) return fail(h, MPCB_E_INVALID, "bad argument (1 <= n <= 64, op 0 = sum, 1 = max)");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (!h->comm) { HIP_TRY(h, hipStreamSynchronize(h->stream)); return MPCB_OK; }
+  const Rccl* R = rccl();
+  HIP_TRY(h, hipMemcpyAsync(h->d_red, values, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  NCCL_TRY(h, R, R->AllReduce(h->d_red, h->d_red, n, ncclDouble, op == 0 ? ncclSum : ncclMax, h->comm, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(values, h->d_red, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPCB_OK;
+}
+
+int mpcb_gathered_z(mpcb_handle* h, int32_t index, const double** d_z) {
+  if (!h || !d_z || index < 0 || index >= (int)h->peers.size()) return fail(h, MPCB_E_INVALID, "not a group leader or bad index");
+  *d_z = h->peers[index]->d_gather;
+  return MPCB_OK;
+}
+
 int mpcb_dev_alloc(mpcb_handle* h, uint64_t bytes, void** dptr) {
   if (!h || !dptr) return MPCB_E_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
@@ -694,6 +923,16 @@ int mpcb_sync(mpcb_handle* h) {
   if (!h) return MPCB_E_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPCB_OK;
+}
+
+int mpcb_stream_wait(mpcb_handle* h, mpcb_handle* other) {
+  if (!h || !other) return MPCB_E_INVALID;
+  if (h->device != other->device) return fail(h, MPCB_E_INVALID, "mpcb_stream_wait: the handles live on different devices");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (!other->ev_sync) HIP_TRY(h, hipEventCreateWithFlags(&other->ev_sync, hipEventDisableTiming));
+  HIP_TRY(h, hipEventRecord(other->ev_sync, other->stream));
+  HIP_TRY(h, hipStreamWaitEvent(h->stream, other->ev_sync, 0));
   return MPCB_OK;
 }
 

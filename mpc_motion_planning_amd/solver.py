@@ -30,6 +30,20 @@ def device_count():
     return lib().mpcb_device_count()
 
 
+def shard_bounds(B, world, rank):
+    """Contiguous slice [lo, hi) of `rank` among `world` (mpcb_shard_bounds: the rule the library itself shards with)."""
+    lo, hi = C.c_int64(), C.c_int64()
+    check(lib().mpcb_shard_bounds(int(B), int(world), int(rank), C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
+
+
+def comm_unique_id():
+    """128 bytes that identify a new RCCL group (ncclGetUniqueId); rank 0 makes them, every rank passes them to comm_init."""
+    buf = C.create_string_buffer(_abi.UNIQUE_ID_BYTES)
+    check(lib().mpcb_comm_unique_id(C.cast(buf, C.c_void_p)))
+    return buf.raw
+
+
 def model_rhs(cfg, x, u):
     """f(x,u) of the configured model (the reference's `mpc_solver.f`, kin.py:159)."""
     x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
@@ -179,8 +193,49 @@ class BatchSolver:
         check(lib().mpcb_solve_device(self._h, B, p(d_x0), p(d_xs), p(d_obs), obs_kind, p(d_z0), p(d_z), p(d_obj), p(d_status),
                                       p(d_iters), p(d_kkt), p(d_lam_g), p(d_lam_x), 1 if sync else 0), self._h)
 
+    # ----- multi-GPU (include/mpcbatch.h, "multi-GPU") ------------------------------------------------------
+    def set_devices(self, ids):
+        """One process driving several devices: solve_batch then shards the batch over them and all-gathers z (RCCL)."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        check(lib().mpcb_set_devices(self._h, iptr(ids), len(ids)), self._h)
+
+    def comm_init(self, unique_id, rank, world):
+        """One process per GPU: join the RCCL group identified by `unique_id` (comm_unique_id() of rank 0)."""
+        buf = C.create_string_buffer(bytes(unique_id), _abi.UNIQUE_ID_BYTES)
+        check(lib().mpcb_comm_init_rank(self._h, C.cast(buf, C.c_void_p), int(rank), int(world)), self._h)
+
+    def comm_info(self):
+        w, r = C.c_int32(), C.c_int32()
+        check(lib().mpcb_comm_info(self._h, C.byref(w), C.byref(r)), self._h)
+        return w.value, r.value
+
+    def allgather(self, d_send, d_recv, count):
+        p = lambda v: v.ptr if isinstance(v, DeviceArray) else C.c_void_p(int(v))   # noqa: E731
+        check(lib().mpcb_allgather(self._h, p(d_send), p(d_recv), int(count)), self._h)
+
+    def allreduce(self, values, op="sum"):
+        """In-place over the ranks on a small float64 array; also a barrier."""
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        check(lib().mpcb_allreduce(self._h, dptr(v), v.size, 0 if op == "sum" else 1), self._h)
+        return v
+
+    def gathered_z(self, index, B):
+        """(device group) the [B, nz] trajectories of the last solve_batch as device `index` of the group holds them after the
+        all-gather, downloaded for inspection."""
+        p = C.c_void_p()
+        check(lib().mpcb_gathered_z(self._h, int(index), C.byref(p)), self._h)
+        G = self.comm_info()[0]
+        longest = max(hi - lo for lo, hi in (shard_bounds(B, G, g) for g in range(G)))
+        raw = np.empty((G * longest, self.nz))
+        check(lib().mpcb_dev_download(self._h, raw.ctypes.data_as(C.c_void_p), p, raw.nbytes), self._h)
+        return np.concatenate([raw[g * longest: g * longest + (hi - lo)] for g, (lo, hi) in enumerate(shard_bounds(B, G, g) for g in range(G))])
+
     def sync(self):
         check(lib().mpcb_sync(self._h), self._h)
+
+    def wait_for(self, other):
+        """This handle's stream waits (on the device) for everything queued so far on `other`'s stream."""
+        check(lib().mpcb_stream_wait(self._h, other._h), self._h)
 
     def timing(self, reset=False):
         n = C.c_int32(); tot = C.c_double(); last = C.c_double()

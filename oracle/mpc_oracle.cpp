@@ -44,6 +44,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <new>
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
@@ -1249,14 +1250,18 @@ int mpco_solve(const mpcb_config* cfg, int32_t B, const double* x0, const double
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : omp_get_max_threads())
 #endif
   for (int b = 0; b < B; ++b) {
-    Solver* s = new Solver(*cfg);
+    // one arena per thread, re-used for every instance (a Solver is ~1 MB: allocating it per instance means an mmap / page-fault
+    // storm per solve)
+    static thread_local void* arena = nullptr;
+    if (!arena) arena = ::operator new(sizeof(Solver));
+    Solver* s = new (arena) Solver(*cfg);
     bool ok = s->init(x0 + (size_t)b * nx, xs + (size_t)b * nx, obs ? obs + b * obs_stride : nullptr, obs_kind,
                       z0 ? z0 + (size_t)b * nz : nullptr);
     if (ok) s->solve(); else s->eval_point();
     s->write(z + (size_t)b * nz, obj ? obj + b : nullptr, status ? status + b : nullptr, iters ? iters + b : nullptr,
              kkt ? kkt + (size_t)b * 4 : nullptr, lam_g ? lam_g + (size_t)b * ng : nullptr,
              lam_x ? lam_x + (size_t)b * nz : nullptr);
-    delete s;
+    s->~Solver();
   }
   return MPCB_OK;
 }

@@ -58,3 +58,19 @@ def test_model_rhs_host():
 
 def test_version_string():
     assert b"gfx950" in _lib.lib().mpcb_version()
+
+
+def test_shard_bounds_of_the_library_match_the_host_rule():
+    """mpcb_shard_bounds (what the library cuts a device group's batch with) against sharding.shard_bounds (what bench.py and
+    the gloo test use): contiguous, covering, sizes differing by at most one."""
+    from mpc_motion_planning_amd.sharding import shard_bounds
+    from mpc_motion_planning_amd import solver
+    for B in (0, 1, 7, 37, 4096, 65537):
+        for W in (1, 2, 3, 8):
+            cuts = [solver.shard_bounds(B, W, r) for r in range(W)]
+            assert cuts == [shard_bounds(B, W, r) for r in range(W)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == B and all(cuts[i][1] == cuts[i + 1][0] for i in range(W - 1))
+    lo, hi = C.c_int64(), C.c_int64()
+    assert _lib.lib().mpcb_shard_bounds(10, 2, 2, C.byref(lo), C.byref(hi)) == _abi.E_INVALID
+    w, r = C.c_int32(), C.c_int32()
+    assert _lib.lib().mpcb_comm_info(None, C.byref(w), C.byref(r)) == _abi.E_INVALID

@@ -42,3 +42,26 @@ def test_two_rank_sharded_solve_and_allgather(tmp_path):
     assert (int(outs[0]["lo"]), int(outs[0]["hi"]), int(outs[1]["lo"]), int(outs[1]["hi"])) == (0, 19, 19, 37)
     for o in outs:                                               # every rank holds every trajectory, bit-identical
         assert np.array_equal(o["z"], ref["z"]) and np.array_equal(o["status"], ref["status"])
+
+
+def _id_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    from mpc_motion_planning_amd.sharding import exchange_unique_id
+    uid = exchange_unique_id(rank, world, lambda: bytes(range(128)), addr="127.0.0.1", port=port)
+    open(os.path.join(out_dir, "id%d.bin" % rank), "wb").write(uid)
+
+
+def test_group_id_travels_from_rank0_over_tcp(tmp_path):
+    """The host channel of the in-library RCCL group (bench.py, N > 1 without torch.distributed): rank 0 hands the 128-byte
+    id to the other ranks over a plain TCP socket."""
+    import multiprocessing as mp
+    world, port = 3, 31017 + (os.getpid() % 500)
+    ctx = mp.get_context("spawn")
+    ps = [ctx.Process(target=_id_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p_ in ps:
+        p_.start()
+    for p_ in ps:
+        p_.join(60)
+        assert p_.exitcode == 0
+    for r in range(world):
+        assert open(os.path.join(tmp_path, "id%d.bin" % r), "rb").read() == bytes(range(128))

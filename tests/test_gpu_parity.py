@@ -7,6 +7,7 @@ both sides stop as soon as IPOPT's SCALED error is <= tol = 1e-8; the objective 
 curvature (Q_x = 10) then leaves x free within ~1e-6, so two runs whose rounding differs stop at different points of
 that ball.  test_tight_tolerance_agreement shows the two paths agree to 1e-8 when tol is tightened."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -547,3 +548,40 @@ def test_two_handles_in_flight_give_the_same_results(gpu_solver_factory):
     for name, r in (("a", ra), ("b", rb)):
         assert np.array_equal(d[name]["st"].download(), r["status"]) and np.array_equal(d[name]["it"].download(), r["iters"])
         assert np.array_equal(d[name]["z"].download(), r["z"])                            # bit for bit: the kernel is deterministic
+
+
+def test_multi_gpu_paths_inside_the_library(gpu_solver_factory):
+    """include/mpcbatch.h "multi-GPU": a device group of this process (mpcb_set_devices -> ncclCommInitAll; shards, solves,
+    all-gathers z) and the one-process-per-GPU group (mpcb_comm_init_rank) on the devices that are visible — on a one-GPU box
+    the groups have one member, the calls and the bookkeeping are the same.  No torch anywhere."""
+    from mpc_motion_planning_amd import solver
+    cfg = default_config(N=30, n_obs=1)
+    x0, xs, obs = scenes.sample_c2(37, seed=33)
+    ref = gpu_solver_factory(cfg).solve_batch(x0, xs, obs, multipliers=True)
+    nd = solver.device_count()
+    g = gpu_solver_factory(cfg); g.set_devices(list(range(nd)))
+    assert g.comm_info() == (nd, 0)
+    r = g.solve_batch(x0, xs, obs, multipliers=True)
+    for k in ("z", "status", "iters", "obj", "lam_g", "lam_x"):
+        assert np.array_equal(r[k], ref[k]), k
+    for i in range(nd):
+        assert np.array_equal(g.gathered_z(i, 37), ref["z"])                 # every device holds every trajectory
+    a = gpu_solver_factory(cfg); a.comm_init(solver.comm_unique_id(), 0, 1)
+    assert a.comm_info() == (1, 0) and list(a.allreduce([1.5, 2.0], "max")) == [1.5, 2.0]
+    s_ = a.device_array((5,)).upload(np.arange(5.0)); d_ = a.device_array((5,))
+    a.allgather(s_, d_, 5); a.sync()
+    assert np.array_equal(d_.download(), np.arange(5.0))
+
+
+def test_bench_runs_its_multi_rank_plumbing_without_torch():
+    """bench.py with the N > 1 plumbing forced on one rank (RCCL group of one inside the library, all-gather per step): the
+    JSON line carries value_without_gather, and torch is never imported."""
+    import subprocess
+    env = dict(os.environ, MPCB_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    code = ("import sys, runpy; sys.argv = ['bench.py', '--steps', '4', '--warmup', '1', '--batch', '512', '--no-cpu-baseline']; "
+            "runpy.run_path(%r, run_name='__main__'); assert 'torch' not in sys.modules, 'bench.py imported torch'" % os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["config"]["value_without_gather"] > 0 and line["value"] > 0 and "RCCL" in line["config"]["collective"]
