@@ -143,6 +143,13 @@ const char* mpcb_last_error(const mpcb_handle* h);   /* h may be NULL: last crea
 int mpcb_set_bounds(mpcb_handle* h, const double* lbx, const double* ubx, int32_t nz,
                     const double* lbg, const double* ubg, int32_t ng);
 
+/* Per-stage step lengths T_0..T_{N-1} (host pointer, n = N; T_i = NULL or n = 0 returns to cfg.T everywhere).  The reference
+ * computes a two-rate grid t_vector when `is_variable_time` is true (kin.py:19-25: steps of T_S, then of T_L) but never uses it:
+ * its shooting rows and rate bounds keep T_S (kin.py:207,116-121).  With a grid set, stage i integrates X_{i+1} = X_i + T_i f,
+ * rate row i is bounded by rate * T_{i-1}, obstacle predictions inside mpcb_closed_loop are taken at the grid's node times and
+ * its plant step uses T_0.  Without one (the default, and what the reference does) everything uses cfg.T. */
+int mpcb_set_time_grid(mpcb_handle* h, const double* T_i, int32_t n);
+
 /* Solve B independent instances (replaces `res = solver(x0=, p=, ...)`, main_cbf_kin_c_sim.py:100).
  *   x0   [B, nx]   initial state  (P[0:nx])
  *   xs   [B, nx]   set-point      (P[nx:2nx])

@@ -24,6 +24,7 @@ SIGNATURES = {
     "mpcb_destroy": (C.c_int, [_H]),
     "mpcb_last_error": (C.c_char_p, [_H]),
     "mpcb_set_bounds": (C.c_int, [_H, _PD, _PD, C.c_int32, _PD, _PD, C.c_int32]),
+    "mpcb_set_time_grid": (C.c_int, [_H, _PD, C.c_int32]),
     "mpcb_solve": (C.c_int, [_H, C.c_int32, _PD, _PD, _PD, C.c_int32, _PD, _PD, _PD, _PI, _PI, _PD, _PD, _PD]),
     "mpcb_solve_device": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),

@@ -83,6 +83,7 @@ class NlpSolver:
         cfg = self._cfg
         nx = cfg.nx()
         bs = self._owner._batch_solver(cfg)
+        bs.set_time_grid(self._owner.stage_lengths() if self._owner.time_grid_in_nlp else None)
         if lbx is not None and ubx is not None and lbg is not None and ubg is not None:
             bs.set_bounds(np.asarray(lbx, dtype=np.float64).reshape(-1), np.asarray(ubx, dtype=np.float64).reshape(-1),
                           np.asarray(lbg, dtype=np.float64).reshape(-1), np.asarray(ubg, dtype=np.float64).reshape(-1))
@@ -150,6 +151,10 @@ class MpcBase:
         # next to them with `gamma = 1.00` (kin.py:235,247-248).  Same switch here: cbf_rows = True selects the commented form.
         self.cbf_rows = False
         self.gamma = 1.0
+        # The reference builds the two-rate grid t_vector when is_variable_time is true (kin.py:19-25) but its NLP keeps T_S in
+        # every shooting row and rate bound (kin.py:207,116-121).  Same default here; time_grid_in_nlp = True makes the grid
+        # effective: stage i integrates over stage_lengths()[i] (mpcb_set_time_grid).
+        self.time_grid_in_nlp = False
         self.f = ModelFunction(self._make_cfg(0))
 
     # ----- configuration of the HIP library from the YAML values ------------------------------------------
@@ -178,6 +183,14 @@ class MpcBase:
             bs = BatchSolver(cfg)
             self._solvers[key] = bs
         return bs
+
+    def stage_lengths(self):
+        """Step length of every stage from t_vector: its differences, the last stage as long as the one before it (the variable
+        grid of kin.py:19-25 has N_p points for N_p stages); T_S everywhere for the fixed grid."""
+        if self.is_variable_time == True:  # noqa: E712
+            d = np.diff(np.asarray(self.t_vector, dtype=np.float64))
+            return np.append(d, d[-1])[: self.N_p]
+        return np.full(int(self.N_p), float(self.T_S))
 
     def generate_ref_path(self, x0, xs):
         """Quintic lane-change reference (kin.py:258-308; never called by the reference's drivers, kept for the surface):

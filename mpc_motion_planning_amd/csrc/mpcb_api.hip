@@ -85,12 +85,11 @@ __global__ __launch_bounds__(128) void mpcb_advance(const mpcb_config c, int B, 
                                                     double* __restrict__ x0, double* __restrict__ z0, double* __restrict__ obs,
                                                     double* __restrict__ x_hist, double* __restrict__ u_hist,
                                                     const int32_t* __restrict__ status, int st_stride, int step, int steps,
-                                                    int move_obs, int hold) {
+                                                    int move_obs, int hold, double T) {
 #pragma clang fp contract(off)   // st = x0 + T*f and x += v*cos(theta)*dt with numpy's roundings (no FMA): bit-equal to the reference's helpers
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const int N = c.N, n_obs = c.n_obs;
-  const double T = c.T;
+  const int N = c.N, n_obs = c.n_obs;     // T: length of the executed step (cfg.T, or T_0 of the time grid)
   double* w = z0 + (size_t)b * nz;
   // the plan that is executed: this step's solution, or (hold) the previous plan kept in z0
   const bool keep = hold && status && status[(size_t)b * st_stride] != MPCB_ST_SOLVED;
@@ -128,17 +127,18 @@ __global__ __launch_bounds__(128) void mpcb_advance(const mpcb_config c, int B, 
 }
 
 // constant-velocity prediction of every obstacle over the horizon: [B, n_obs, 6] -> [B, n_obs, N+1, 6]
-__global__ void mpcb_predict_obs(int total, int N, double T, const double* __restrict__ obs, double* __restrict__ traj) {
+__global__ void mpcb_predict_obs(int total, int N, double T, const double* __restrict__ tgrid, const double* __restrict__ obs, double* __restrict__ traj) {
 #pragma clang fp contract(off)   // next_x = x + v*cos(theta)*dt, two roundings per step as in Obs_prediction.py:27-28
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const double* o = obs + (size_t)i * 6;
   double x = o[0], y = o[1];
-  const double sx = o[3] * cos(o[2]) * T, sy = o[3] * sin(o[2]) * T;
+  const double vx = o[3] * cos(o[2]), vy = o[3] * sin(o[2]);
   for (int k = 0; k <= N; ++k) {
     double* t = traj + ((size_t)i * (N + 1) + k) * 6;
     t[0] = x; t[1] = y; t[2] = o[2]; t[3] = o[3]; t[4] = o[4]; t[5] = o[5];
-    x += sx; y += sy;
+    const double Tk = tgrid ? tgrid[k < N ? k : N - 1] : T;                      // node times of the time grid, or k * T
+    x += vx * Tk; y += vy * Tk;
   }
 }
 
@@ -167,6 +167,7 @@ struct mpcb_handle {
   std::vector<mpcb_handle*> peers;
   double* d_gather = nullptr; size_t gather_cap = 0;   // (b): [world, longest shard, nz] all-gather target on this device
   double* d_red = nullptr;                             // small device buffer for mpcb_allreduce
+  double* d_tgrid = nullptr; double T0 = 0;            // mpcb_set_time_grid: [N] step lengths on the device, T_0 for the plant step
   hipEvent_t ev_sync = nullptr;                        // mpcb_stream_wait: marks "everything queued so far on this stream"
   size_t gathered_rows = 0;                            // (b): rows per shard block of the last gather, B of that solve
   int64_t gathered_B = 0;
@@ -254,8 +255,11 @@ int check_cfg(mpcb_handle* h, const mpcb_config* c) {
   return MPCB_OK;
 }
 
+bool is_gen(const mpcb_config& c) { return c.model == MPCB_MODEL_KIN && c.obs_mode == MPCB_OBS_DCBF && c.gamma < 1.0 - 1e-12 && c.n_obs > 0; }
+
 size_t lds_bytes(const mpcb_config& c, int nz) {
-  return (size_t)(c.model == MPCB_MODEL_DYN ? mpcbk::layout_dyn(c.N).total : mpcbk::layout_kin(c.N, nz).total) * sizeof(double);
+  return (size_t)(c.model == MPCB_MODEL_DYN ? mpcbk::layout_dyn(c.N, false, mpcbk::obs_in_lds(mpcbk::obs_capacity_dyn(c.n_obs))).total
+                                             : mpcbk::layout_kin(c.N, nz, false, mpcbk::obs_in_lds(mpcbk::obs_capacity_kin(c.n_obs, is_gen(c)))).total) * sizeof(double);
 }
 
 // oldest recorded pair -> total_ms / last_ms / launches
@@ -336,7 +340,8 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in) {
     // restoration pass over the same grid: instances that ended the first pass with MPCB_ST_NEEDS_RESTO continue, the others return
     a.pass = 1;
     const bool dyn = h->cfg.model == MPCB_MODEL_DYN;
-    const size_t lds2 = (size_t)(dyn ? mpcbk::layout_dyn(h->cfg.N, true).total : mpcbk::layout_kin(h->cfg.N, h->nz, true).total) * sizeof(double);
+    const size_t lds2 = (size_t)(dyn ? mpcbk::layout_dyn(h->cfg.N, true, mpcbk::obs_in_lds(mpcbk::obs_capacity_dyn(n))).total
+                                     : mpcbk::layout_kin(h->cfg.N, h->nz, true, mpcbk::obs_in_lds(mpcbk::obs_capacity_kin(n, is_gen(h->cfg)))).total) * sizeof(double);
     if (lds2 > 160 * 1024) return fail(h, MPCB_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds2);
     const bool gen = h->cfg.obs_mode == MPCB_OBS_DCBF && h->cfg.gamma < 1.0 - 1e-12 && n > 0;
     if (dyn) {
@@ -387,7 +392,7 @@ int solve_on_device(mpcb_handle* h, int32_t B, const double* d_x0, const double*
   HIP_TRY(h, hipSetDevice(h->device));
   MpcbKArgs a;
   a.cfg = h->cfg; a.B = B; a.nz = h->nz; a.ng = h->ng; a.obs_kind = obs_kind;
-  a.want_mult = (d_lam_g || d_lam_x) ? 1 : 0; a.trace_instance = -1; a.trace = nullptr; a.st_stride = st_stride;
+  a.want_mult = (d_lam_g || d_lam_x) ? 1 : 0; a.trace_instance = -1; a.trace = nullptr; a.st_stride = st_stride; a.tgrid = h->d_tgrid;
   a.x0 = d_x0; a.xs = d_xs; a.obs = d_obs; a.z0 = d_z0;
   a.z = d_z; a.obj = d_obj; a.kkt = d_kkt; a.lam_g = d_lam_g; a.lam_x = d_lam_x; a.status = d_status; a.iters = d_iters;
   return launch_solve(h, a);
@@ -483,6 +488,7 @@ int mpcb_destroy(mpcb_handle* h) {
   if (h->d_gather) (void)hipFree(h->d_gather);
   if (h->d_red) (void)hipFree(h->d_red);
   if (h->ev_sync) (void)hipEventDestroy(h->ev_sync);
+  if (h->d_tgrid) (void)hipFree(h->d_tgrid);
   if (h->d_work) (void)hipFree(h->d_work);
   if (h->d_st_own) (void)hipFree(h->d_st_own);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -549,6 +555,24 @@ int mpcb_set_bounds(mpcb_handle* h, const double* lbx, const double* ubx, int32_
   int rc = check_cfg(h, &c);
   if (rc != MPCB_OK) { h->cfg = saved; return rc; }
   h->cfg = c;
+  return MPCB_OK;
+}
+
+int mpcb_set_time_grid(mpcb_handle* h, const double* T_i, int32_t n) {
+  if (!h) return MPCB_E_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (!T_i || n == 0) {
+    if (h->d_tgrid) { HIP_TRY(h, hipFree(h->d_tgrid)); h->d_tgrid = nullptr; }
+  } else {
+    if (n != h->cfg.N) return fail(h, MPCB_E_INVALID, "the time grid has %d entries, the NLP has N = %d stages", n, h->cfg.N);
+    for (int i = 0; i < n; ++i) if (!(T_i[i] > 0) || !std::isfinite(T_i[i])) return fail(h, MPCB_E_INVALID, "T_%d = %g must be positive and finite", i, T_i[i]);
+    if (!h->d_tgrid) HIP_TRY(h, hipMalloc(&h->d_tgrid, (size_t)h->cfg.N * sizeof(double)));
+    HIP_TRY(h, hipMemcpy(h->d_tgrid, T_i, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    h->T0 = T_i[0];
+  }
+  for (auto* p : h->peers) { int rc = mpcb_set_time_grid(p, T_i, n); if (rc != MPCB_OK) return fail(h, rc, "device %d: %s", p->device, p->err.c_str()); }
+  HIP_TRY(h, hipSetDevice(h->device));
   return MPCB_OK;
 }
 
@@ -721,7 +745,7 @@ int mpcb_solve_trace(mpcb_handle* h, const double* x0, const double* xs, const d
   if (d_z0) HIP_TRY(h, hipMemcpyAsync(d_z0, z0, nz * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(h, hipMemsetAsync(d_tr, 0, n_tr * 8, s));
   MpcbKArgs a;
-  a.cfg = h->cfg; a.B = 1; a.nz = nz; a.ng = h->ng; a.obs_kind = obs_kind; a.want_mult = 0; a.trace_instance = 0; a.trace = d_tr; a.st_stride = 1;
+  a.cfg = h->cfg; a.B = 1; a.nz = nz; a.ng = h->ng; a.obs_kind = obs_kind; a.want_mult = 0; a.trace_instance = 0; a.trace = d_tr; a.st_stride = 1; a.tgrid = h->d_tgrid;
   a.x0 = d_x0; a.xs = d_xs; a.obs = d_obs; a.z0 = d_z0; a.z = d_z; a.obj = nullptr; a.kkt = nullptr; a.lam_g = nullptr; a.lam_x = nullptr;
   a.status = d_st; a.iters = d_it;
   rc = launch_solve(h, a);
@@ -769,11 +793,12 @@ int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps, const double* x0,
   HIP_TRY(h, hipMemcpy2DAsync(d_xh, (size_t)(steps + 1) * nx * 8, d_x0, (size_t)nx * 8, (size_t)nx * 8, B, hipMemcpyDeviceToDevice, s));
   const int move = obs_motion == MPCB_OBSMOVE_STATIC ? 0 : (flags & MPCB_CL_ADVANCE_FIRST_ONLY) ? 2 : 1;
   const int hold = (flags & MPCB_CL_HOLD_ON_FAILURE) ? 1 : 0;
+  const double Tstep = h->d_tgrid ? h->T0 : h->cfg.T;
   for (int t = 0; t < steps; ++t) {
     const double* obs_in = d_obs; int kind = MPCB_OBSIN_STATIC;
     if (predict && no) {
       const int total = B * no;
-      hipLaunchKernelGGL(mpcb_predict_obs, dim3((total + 255) / 256), dim3(256), 0, s, total, N, h->cfg.T, d_obs, d_traj);
+      hipLaunchKernelGGL(mpcb_predict_obs, dim3((total + 255) / 256), dim3(256), 0, s, total, N, h->cfg.T, h->d_tgrid, d_obs, d_traj);
       obs_in = d_traj; kind = MPCB_OBSIN_PREDICTED;
     }
     // the solve kernel writes status / iters of step t straight into column t of the [B, steps] histories
@@ -781,10 +806,10 @@ int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps, const double* x0,
     if (rc != MPCB_OK) return rc;
     if (nx == 6)
       hipLaunchKernelGGL(mpcb_advance<6>, dim3((B + 127) / 128), dim3(128), 0, s, h->cfg, B, nz, d_z, d_x0, d_z0, d_obs, d_xh, d_uh,
-                         d_st + t, steps, t, steps, move, hold);
+                         d_st + t, steps, t, steps, move, hold, Tstep);
     else
       hipLaunchKernelGGL(mpcb_advance<4>, dim3((B + 127) / 128), dim3(128), 0, s, h->cfg, B, nz, d_z, d_x0, d_z0, d_obs, d_xh, d_uh,
-                         d_st + t, steps, t, steps, move, hold);
+                         d_st + t, steps, t, steps, move, hold, Tstep);
     HIP_TRY(h, hipGetLastError());
   }
   if (x_hist) HIP_TRY(h, hipMemcpyAsync(x_hist, d_xh, (size_t)B * (steps + 1) * nx * 8, hipMemcpyDeviceToHost, s));

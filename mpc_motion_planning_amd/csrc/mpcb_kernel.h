@@ -35,6 +35,7 @@ struct MpcbKArgs {
   int32_t st_stride;   // status / iters of instance b go to index b * st_stride (the closed loop writes its [B, steps] histories directly)
   int32_t pass;        // 0: first pass (main phase; an instance that needs the restoration phase ends with MPCB_ST_NEEDS_RESTO and a
                        //    hand-over record in `work`); 1: restoration pass (RESTO kernel instantiation, only those instances run)
+  const double* tgrid; // [N] step length of every stage (mpcb_set_time_grid), NULL = cfg.T everywhere
   double* work;        // [B][WK_SIZE] hand-over records between the passes (device scratch of the handle), NULL when cfg.restoration == 0
   const double *x0, *xs, *obs, *z0;
   double *z, *obj, *kkt, *lam_g, *lam_x;
@@ -89,16 +90,21 @@ enum KinEnt {
 //                    without one), pad slot 43 (p stores of non-affine lanes), pad slots 44..47 (P stores of lanes without a
 //                    P entry)
 //   fw  [N+1][FWS]   everything the forward roll-out reads for stage k, contiguous: K (2x6), kff (2), a02 a03 a12 a13 a23 b20,
-//                    d0..d3, then 4 pad slots for the K stores of lanes without a K entry
+//                    d0..d3, then 4 pad slots for the K stores of lanes without a K entry, the stage's step length T_k, one spare
 constexpr int PST = 48, PS_P = 36, PS_ZERO = 42, PS_PADP = 43, PS_PAD = 44;
-constexpr int FWS = 28, FW_KFF = 12, FW_A = 14, FW_D = 20, FW_PAD = 24, WSZ = 72, W_ZERO = 64;
+constexpr int FWS = 30, FW_KFF = 12, FW_A = 14, FW_D = 20, FW_PAD = 24, FW_T = 28, WSZ = 72, W_ZERO = 64;
 // constant block: uniform numbers of the instance that the node-parallel phases read from LDS (one ds_read, short live range)
 // instead of holding ~25 SGPR pairs through the whole solve
 constexpr int CS_WQ = 0, CS_WR = 4, CS_WDR = 6, CS_Q = 8, CS_R = 12, CS_DR = 14, CS_UL = 16, CS_XS = 18, CSZ = 24;
 struct Layout {
-  int ld, ent, Pst, fw, W, cst, filt, zbuf, ct, total;
+  int ld, ent, Pst, fw, W, cst, filt, zbuf, ct, obl, total;
 };
-MPCB_HD Layout layout_kin(int N, int nz, bool resto = false) {
+// obstacle-row capacity of the kernel instantiation that serves n obstacles, and how many of its obstacle constants (centre, 1/sX^2,
+// 1/sY^2: four doubles per obstacle and lane) live in LDS instead of registers: none up to 3, all of them above (the 5- and
+// 8-obstacle instantiations are far beyond the register file otherwise)
+MPCB_HD int obs_capacity_kin(int n, bool gen = false) { return n <= 0 ? (gen ? 1 : 0) : n == 1 ? 1 : n <= 3 ? 3 : (n <= 5 && !gen) ? 5 : 8; }   // (no GEN<5> instantiation)
+MPCB_HD int obs_in_lds(int capacity) { return capacity > 3 ? capacity : 0; }
+MPCB_HD Layout layout_kin(int N, int nz, bool resto = false, int nobl = 0) {
   Layout L;
   const int N1 = N + 1;
   L.ld = N1 | 1;
@@ -112,6 +118,7 @@ MPCB_HD Layout layout_kin(int N, int nz, bool resto = false) {
   L.zbuf = L.Pst;                    // staging of z rows aliases the Riccati storage (used before / after the loop)
   (void)nz;
   L.ct = o; if (resto) o += CT_ROWS * 64;
+  L.obl = o; o += 4 * nobl * 64;
   L.total = o;
   return L;
 }
@@ -122,6 +129,14 @@ MPCB_DEV Bnd mk_bnd(double L, double U, double relax) {
   q.hasL = L > -1e300; q.hasU = U < 1e300; q.on = q.hasL || q.hasU;
   q.L = wv::uni(q.hasL ? L - relax * fmax(1.0, fabs(L)) : L);
   q.U = wv::uni(q.hasU ? U + relax * fmax(1.0, fabs(U)) : U);
+  return q;
+}
+// the same for bounds that differ from lane to lane (rate rows under a time grid)
+MPCB_DEV Bnd mk_bnd_lane(double L, double U, double relax) {
+  Bnd q;
+  q.hasL = L > -1e300; q.hasU = U < 1e300; q.on = q.hasL || q.hasU;
+  q.L = q.hasL ? L - relax * fmax(1.0, fabs(L)) : L;
+  q.U = q.hasU ? U + relax * fmax(1.0, fabs(U)) : U;
   return q;
 }
 MPCB_DEV double push_in(const Bnd& q, double v, double k1, double k2) {
@@ -195,10 +210,12 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   const int N = c.N, lane = wv::lane(), k = lane;
   const int nz = a.nz, nobs = c.n_obs;
   if (RESTO && a.status[(size_t)b * a.st_stride] != MPCB_ST_NEEDS_RESTO) return;     // wave-uniform: this instance is done
-  const Layout L = layout_kin(N, nz, RESTO);
+  constexpr bool OBL = NOBS > 3;                  // obstacle constants in LDS ([4 * j + q][lane]) instead of registers
+  const Layout L = layout_kin(N, nz, RESTO, obs_in_lds(NOBS));
   const int ld = L.ld;
   double* ent = lds + L.ent;
-  const double T = c.T, il = 1.0 / c.veh_l;
+  // step length of this lane's stage: cfg.T, or the stage's entry of the time grid (lanes past the last stage take its value)
+  const double T = a.tgrid ? a.tgrid[k < N ? k : N - 1] : c.T, il = 1.0 / c.veh_l;
 
   const bool isnode = k <= N, hasu = k < N, xnode = k >= 1 && k <= N, xcost = k >= 1 && k < N;
   const double* gx0 = a.x0 + (size_t)b * NX;
@@ -214,22 +231,31 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   else if (GEN) { obs_node = k <= N - 1; ostep = k; }
   else { obs_node = k >= 1 && k - 1 <= last_row; ostep = k - 1; }
   obs_node = obs_node && isnode;
-  double ox[NOB], oy[NOB], ix2[NOB], iy2[NOB];
+  double ox_[OBL ? 1 : NOB], oy_[OBL ? 1 : NOB], ix2_[OBL ? 1 : NOB], iy2_[OBL ? 1 : NOB];
+  double* obl = lds + L.obl;
+  auto OC = [&](int j, int q) -> double& {          // constant q (0 centre x, 1 centre y, 2 1/sX^2, 3 1/sY^2) of obstacle slot j
+    if constexpr (OBL) return obl[(4 * j + q) * 64 + lane];
+    else return q == 0 ? ox_[j] : q == 1 ? oy_[j] : q == 2 ? ix2_[j] : iy2_[j];
+  };
+#define ox(j) OC(j, 0)
+#define oy(j) OC(j, 1)
+#define ix2(j) OC(j, 2)
+#define iy2(j) OC(j, 3)
 #pragma unroll
   for (int j = 0; j < NOBS; ++j) {
-    ox[j] = 0; oy[j] = 0; ix2[j] = 0; iy2[j] = 0;
+    ox(j) = 0; oy(j) = 0; ix2(j) = 0; iy2(j) = 0;
     if (j < nobs && obs_node) {
       const double* q = (a.obs_kind == MPCB_OBSIN_PREDICTED)
                             ? a.obs + (((size_t)b * nobs + j) * (N + 1) + ostep) * 6
                             : a.obs + ((size_t)b * nobs + j) * 6;
       double sx = c.obs_sx_fixed > 0 ? c.obs_sx_fixed : c.ego_hl + q[4] / 2 + c.safe_disl;
       double sy = c.obs_sy_fixed > 0 ? c.obs_sy_fixed : c.ego_hw + q[5] / 2 + c.safe_disw;
-      ox[j] = q[0]; oy[j] = q[1]; ix2[j] = 1.0 / (sx * sx); iy2[j] = 1.0 / (sy * sy);
+      ox(j) = q[0]; oy(j) = q[1]; ix2(j) = 1.0 / (sx * sx); iy2(j) = 1.0 / (sy * sy);
     }
   }
   auto hval = [&](int j, double px, double py) {
-    double dx = px - ox[j], dy = py - oy[j];
-    return dx * dx * ix2[j] + dy * dy * iy2[j] - 1.0;
+    double dx = px - ox(j), dy = py - oy(j);
+    return dx * dx * ix2(j) + dy * dy * iy2(j) - 1.0;
   };
   const double omg = GEN ? 1.0 - c.gamma : 0.0;                     // (1 - gamma) of the general CBF row
   // value of obstacle row j at a node with position (px,py), heading sin/cos (s_,c_) and speed v
@@ -370,7 +396,10 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   // bounds (uniform)
   const Bnd qU0 = mk_bnd(c.u_lo[0], c.u_hi[0], c.bound_relax), qU1 = mk_bnd(c.u_lo[1], c.u_hi[1], c.bound_relax);
   const Bnd qY = mk_bnd(c.x_lo[1], c.x_hi[1], c.bound_relax), qV = mk_bnd(c.x_lo[3], c.x_hi[3], c.bound_relax);
-  const Bnd qR = mk_bnd(c.du_lo[0], c.du_hi[0], c.bound_relax);
+  // rate row k compares U_k - U_{k-1} with rate * (time between the two controls): cfg.du_* are rate * cfg.T (kin.py:116-121),
+  // with a time grid the bounds of lane k scale by T_{k-1} / cfg.T (1 exactly without a grid)
+  const double rsc = a.tgrid ? wv::shfl(T, k - 1) / c.T : 1.0;
+  const Bnd qR = mk_bnd_lane(c.du_lo[0] * rsc, c.du_hi[0] * rsc, c.bound_relax);
   const Bnd qO = mk_bnd((GEN ? c.gamma : 1.0) * c.obs_hmin, 1e308, c.bound_relax);
   const bool bu0_on = hasu && qU0.on, bu1_on = hasu && qU1.on, by_on = xnode && qY.on, bv_on = xnode && qV.on;
   const bool rr_on = xcost && qR.on;
@@ -434,11 +463,11 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   auto row_grads = [&](double sp_, double cp_) {
 #pragma unroll
     for (int j = 0; j < NOBS; ++j) if (ro_on[j]) {
-      const double dpx = 2 * (X[0] - ox[j]) * ix2[j], dpy = 2 * (X[1] - oy[j]) * iy2[j];
+      const double dpx = 2 * (X[0] - ox(j)) * ix2(j), dpy = 2 * (X[1] - oy(j)) * iy2(j);
       if (!GEN) { gO0[j] = dpx; gO1[j] = dpy; }
       else {
         const double v = X[3];
-        const double dqx = 2 * (X[0] + T * (v * cp_) - ox[j]) * ix2[j], dqy = 2 * (X[1] + T * (v * sp_) - oy[j]) * iy2[j];
+        const double dqx = 2 * (X[0] + T * (v * cp_) - ox(j)) * ix2(j), dqy = 2 * (X[1] + T * (v * sp_) - oy(j)) * iy2(j);
         gO0[j] = dqx - omg * dpx; gO1[j] = dqy - omg * dpy;
         gO2[j] = T * v * (dqy * cp_ - dqx * sp_); gO3[j] = T * (dqx * cp_ + dqy * sp_);
       }
@@ -939,25 +968,25 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
             sig *= kap; gb -= sig * rt;
           } else gb -= sig * rO[j];
           if (!GEN) {
-            hxx += sig * gO0[j] * gO0[j] - vO[j] * 2 * ix2[j];
+            hxx += sig * gO0[j] * gO0[j] - vO[j] * 2 * ix2(j);
             hxy += sig * gO0[j] * gO1[j];
-            hyy += sig * gO1[j] * gO1[j] - vO[j] * 2 * iy2[j];
+            hyy += sig * gO1[j] * gO1[j] - vO[j] * 2 * iy2(j);
             g[0] -= gb * gO0[j]; g[1] -= gb * gO1[j];
           } else {
             // sig g g^T - v d2c, c = h(q) - (1-gamma) h(p), q = p + T v (cos phi, sin phi)
             const double v = X[3], y = vO[j], Tv = T * v;
-            const double dqx = 2 * (X[0] + Tv * cp - ox[j]) * ix2[j], dqy = 2 * (X[1] + Tv * sp - oy[j]) * iy2[j];
+            const double dqx = 2 * (X[0] + Tv * cp - ox(j)) * ix2(j), dqy = 2 * (X[1] + Tv * sp - oy(j)) * iy2(j);
             const double g0 = gO0[j], g1 = gO1[j], g2 = gO2[j], g3 = gO3[j];
-            hxx += sig * g0 * g0 - y * (2 * c.gamma * ix2[j]);
+            hxx += sig * g0 * g0 - y * (2 * c.gamma * ix2(j));
             hxy += sig * g0 * g1;
-            hyy += sig * g1 * g1 - y * (2 * c.gamma * iy2[j]);
-            hxp += sig * g0 * g2 - y * (-2 * ix2[j] * Tv * sp);
-            hxv += sig * g0 * g3 - y * (2 * ix2[j] * T * cp);
-            hyp += sig * g1 * g2 - y * (2 * iy2[j] * Tv * cp);
-            hyv += sig * g1 * g3 - y * (2 * iy2[j] * T * sp);
-            hpp += sig * g2 * g2 - y * (2 * Tv * Tv * (ix2[j] * sp * sp + iy2[j] * cp * cp) - Tv * (dqx * cp + dqy * sp));
-            hpv += sig * g2 * g3 - y * (T * (dqy * cp - dqx * sp) + 2 * T * Tv * sp * cp * (iy2[j] - ix2[j]));
-            hvv += sig * g3 * g3 - y * (2 * T * T * (ix2[j] * cp * cp + iy2[j] * sp * sp));
+            hyy += sig * g1 * g1 - y * (2 * c.gamma * iy2(j));
+            hxp += sig * g0 * g2 - y * (-2 * ix2(j) * Tv * sp);
+            hxv += sig * g0 * g3 - y * (2 * ix2(j) * T * cp);
+            hyp += sig * g1 * g2 - y * (2 * iy2(j) * Tv * cp);
+            hyv += sig * g1 * g3 - y * (2 * iy2(j) * T * sp);
+            hpp += sig * g2 * g2 - y * (2 * Tv * Tv * (ix2(j) * sp * sp + iy2(j) * cp * cp) - Tv * (dqx * cp + dqy * sp));
+            hpv += sig * g2 * g3 - y * (T * (dqy * cp - dqx * sp) + 2 * T * Tv * sp * cp * (iy2(j) - ix2(j)));
+            hvv += sig * g3 * g3 - y * (2 * T * T * (ix2(j) * cp * cp + iy2(j) * sp * sp));
             g[0] -= gb * g0; g[1] -= gb * g1; g[2] -= gb * g2; g[3] -= gb * g3;
           }
         }
@@ -974,6 +1003,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           fk[FW_A + 3] = hasu ? a13 : 0.0; fk[FW_A + 4] = hasu ? a23 : 0.0; fk[FW_A + 5] = hasu ? b20 : 0.0;
 #pragma unroll
           for (int i = 0; i < NX; ++i) fk[FW_D + i] = dfc[i];
+          fk[FW_T] = T;
           Pst[k * PST + PS_ZERO] = 0.0;
           ent[E_HXY * ld + k] = hxy; ent[E_HPV * ld + k] = hpv; ent[E_HVD * ld + k] = hvd;
           ent[E_H44 * ld + k] = h44; ent[E_H55 * ld + k] = h55; ent[E_H46 * ld + k] = h46; ent[E_H57 * ld + k] = h57;
@@ -1101,14 +1131,14 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       double dX[NX] = {0, 0, 0, 0}, dU[NU] = {0, 0};
       {
         // 24 table values per stage, none of them on the recursion: prefetched one stage ahead (ping-pong registers)
-        struct FwEnt { double K[2 * NA], kf0, kf1, a02, a03, a12, a13, a23, b20, d0, d1, d2, d3; };
+        struct FwEnt { double K[2 * NA], kf0, kf1, a02, a03, a12, a13, a23, b20, d0, d1, d2, d3, Ts; };
         auto load_fw = [&](int s, FwEnt& f) {
           const double* q = fw + s * FWS;                // 24 contiguous doubles, uniform address: wide LDS reads
 #pragma unroll
           for (int r = 0; r < 2 * NA; ++r) f.K[r] = q[r];
           f.kf0 = q[FW_KFF]; f.kf1 = q[FW_KFF + 1];
           f.a02 = q[FW_A]; f.a03 = q[FW_A + 1]; f.a12 = q[FW_A + 2]; f.a13 = q[FW_A + 3]; f.a23 = q[FW_A + 4]; f.b20 = q[FW_A + 5];
-          f.d0 = q[FW_D]; f.d1 = q[FW_D + 1]; f.d2 = q[FW_D + 2]; f.d3 = q[FW_D + 3];
+          f.d0 = q[FW_D]; f.d1 = q[FW_D + 1]; f.d2 = q[FW_D + 2]; f.d3 = q[FW_D + 3]; f.Ts = q[FW_T];
         };
         double dx0 = 0, dx1 = 0, dx2 = 0, dx3 = 0, dx4 = 0, dx5 = 0;
         auto fstage = [&](int s, const FwEnt& f, FwEnt& nxt) {
@@ -1119,7 +1149,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           const double n0 = fma(f.a03, dx3, fma(f.a02, dx2, dx0 + f.d0));
           const double n1 = fma(f.a13, dx3, fma(f.a12, dx2, dx1 + f.d1));
           const double n2 = fma(f.b20, du0, fma(f.a23, dx3, dx2 + f.d2));
-          const double n3 = fma(T, du1, dx3 + f.d3);
+          const double n3 = fma(f.Ts, du1, dx3 + f.d3);
           if (k == s) { dU[0] = du0; dU[1] = du1; }
           if (k == s + 1) { dX[0] = n0; dX[1] = n1; dX[2] = n2; dX[3] = n3; }
           dx0 = n0; dx1 = n1; dx2 = n2; dx3 = n3; dx4 = du0; dx5 = du1;
@@ -1406,7 +1436,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
 #pragma unroll
       for (int j = 0; j < NOBS; ++j) {
         const double vp = wv::shfl(ro_on[j] ? vO[j] : 0.0, k - 1);
-        const double oxp = wv::shfl(ox[j], k - 1), oyp = wv::shfl(oy[j], k - 1), ixp = wv::shfl(ix2[j], k - 1), iyp = wv::shfl(iy2[j], k - 1);
+        const double oxp = wv::shfl(ox(j), k - 1), oyp = wv::shfl(oy(j), k - 1), ixp = wv::shfl(ix2(j), k - 1), iyp = wv::shfl(iy2(j), k - 1);
         if (k >= 2) { cx += vp * 2 * (X[0] - oxp) * ixp; cy += vp * 2 * (X[1] - oyp) * iyp; }
       }
     }
@@ -1428,3 +1458,8 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     }
   }
 }
+#undef ox
+#undef oy
+#undef ix2
+#undef iy2
+

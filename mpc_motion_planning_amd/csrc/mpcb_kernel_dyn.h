@@ -33,13 +33,14 @@ enum DynEnt {
 // LDS layout (doubles):
 //   Pst [N+1][66]  P_k (8x8) + 2 pad   pst [N+1][10]  p_k (8), slot 8 = permanent 0.0, slot 9 pad
 //   fw  [N+1][DFWS] per-stage numbers of the forward roll-out, contiguous: K (2x8), kff (2), the 14 A entries, b4 b5, d (6), pad
-constexpr int DPST = 66 /* P_k 8x8 + 2 pad slots for the stores of the lanes below the diagonal */, DPSS = 10, DFWS = 44, DFW_KFF = 16, DFW_A = 18, DFW_B = 32, DFW_D = 34, DFW_PAD = 40, DWSZ = 64, DWU = 16 + 16;
+constexpr int DPST = 66 /* P_k 8x8 + 2 pad slots for the stores of the lanes below the diagonal */, DPSS = 10, DFWS = 46, DFW_KFF = 16, DFW_A = 18, DFW_B = 32, DFW_D = 34, DFW_PAD = 40, DFW_T = 44, DWSZ = 64, DWU = 16 + 16;
 // constant block (as in the kin kernel): cost weights, reference state and last control, read from LDS by the node-parallel phases
 constexpr int DCS_WQ = 0, DCS_WR = 6, DCS_WDR = 8, DCS_Q = 10, DCS_R = 16, DCS_DR = 18, DCS_UL = 20, DCS_XS = 22, DCSZ = 28;
 // per-node cost table of the RESTO instantiation, [row][64] (see CostRow in mpcb_kernel.h)
 enum DynCostRow { DCT_WQ = 0, DCT_XR = 6, DCT_WR = 12, DCT_UR = 14, DCT_QQ = 16, DCT_RR = 22, DCT_WDR = 24, DCT_DRR = 26, DCT_ROWS = 28 };
-struct LayoutDyn { int ld, ent, Pst, pst, fw, W, Wu, cst, filt, zbuf, ct, total; };
-MPCB_HD LayoutDyn layout_dyn(int N, bool resto = false) {
+struct LayoutDyn { int ld, ent, Pst, pst, fw, W, Wu, cst, filt, zbuf, ct, obl, total; };
+MPCB_HD int obs_capacity_dyn(int n) { return n <= 1 ? 1 : n <= 3 ? 3 : n <= 5 ? 5 : 8; }
+MPCB_HD LayoutDyn layout_dyn(int N, bool resto = false, int nobl = 0) {
   LayoutDyn L;
   const int N1 = N + 1, NA = 8;
   L.ld = N1 | 1;
@@ -54,6 +55,7 @@ MPCB_HD LayoutDyn layout_dyn(int N, bool resto = false) {
   L.ent = o; o += DYN_NENT * L.ld;
   L.zbuf = L.Pst;
   L.ct = o; if (resto) o += DCT_ROWS * 64;
+  L.obl = o; o += 4 * nobl * 64;
   L.total = o;
   return L;
 }
@@ -78,8 +80,8 @@ MPCB_DEV void dyn_eval(const mpcb_config& c, const double* X, const double* U, D
   e.Fr2 = 2.0 * cR * ar * (3.0 * a2r - ar * ar) * qr * qr * qr;
 }
 // F = X + T f(X, U)                                                                          dyn.py:165-170,227
-MPCB_DEV void dyn_F(const mpcb_config& c, const double* X, const double* U, const DynEval& e, double* F) {
-  const double T = c.T, vx = X[3], vy = X[4], r = X[5];
+MPCB_DEV void dyn_F(const mpcb_config& c, const double T, const double* X, const double* U, const DynEval& e, double* F) {
+  const double vx = X[3], vy = X[4], r = X[5];
   F[0] = X[0] + T * (vx * e.cp - vy * e.sp);
   F[1] = X[1] + T * (vx * e.sp + vy * e.cp);
   F[2] = X[2] + T * r;
@@ -88,8 +90,8 @@ MPCB_DEV void dyn_F(const mpcb_config& c, const double* X, const double* U, cons
   F[5] = X[5] + T * ((2.0 / c.veh_Iz) * (c.veh_lf * e.Ff - c.veh_lr * e.Fr));
 }
 struct DynJac { double a02, a03, a04, a12, a13, a14, a34, a35, a43, a44, a45, a53, a54, a55, b4, b5; };
-MPCB_DEV void dyn_jac(const mpcb_config& c, const double* X, const DynEval& e, DynJac& J) {
-  const double T = c.T, vx = X[3], vy = X[4], r = X[5], k4 = 2.0 / c.veh_m, k5 = 2.0 / c.veh_Iz, lf = c.veh_lf, lr = c.veh_lr;
+MPCB_DEV void dyn_jac(const mpcb_config& c, const double T, const double* X, const DynEval& e, DynJac& J) {
+  const double vx = X[3], vy = X[4], r = X[5], k4 = 2.0 / c.veh_m, k5 = 2.0 / c.veh_Iz, lf = c.veh_lf, lr = c.veh_lr;
   const double i2 = e.ivx * e.ivx;
   const double afx = e.pf * i2, afy = -e.ivx, afr = -lf * e.ivx, arx = e.pr * i2, ary = -e.ivx, arr = lr * e.ivx;
   J.a02 = T * (-vx * e.sp - vy * e.cp); J.a03 = T * e.cp; J.a04 = -T * e.sp;
@@ -106,8 +108,8 @@ MPCB_DEV void dyn_jac(const mpcb_config& c, const double* X, const DynEval& e, D
 }
 // sum_a lam_a T d2 f_a: entries over (phi=2, vx=3, vy=4, r=5, delta=8 in stage numbering)
 struct DynHess { double h22, h23, h24, h33, h34, h35, h44, h45, h55, h38, h48, h58, h88; };
-MPCB_DEV void dyn_hess(const mpcb_config& c, const double* X, const DynEval& e, const double* l, DynHess& H) {
-  const double T = c.T, vx = X[3], vy = X[4], k4 = 2.0 / c.veh_m, k5 = 2.0 / c.veh_Iz, lf = c.veh_lf, lr = c.veh_lr;
+MPCB_DEV void dyn_hess(const mpcb_config& c, const double T, const double* X, const DynEval& e, const double* l, DynHess& H) {
+  const double vx = X[3], vy = X[4], k4 = 2.0 / c.veh_m, k5 = 2.0 / c.veh_Iz, lf = c.veh_lf, lr = c.veh_lr;
   const double i2 = e.ivx * e.ivx, i3 = i2 * e.ivx;
   const double af[3] = {e.pf * i2, -e.ivx, -lf * e.ivx}, ar[3] = {e.pr * i2, -e.ivx, lr * e.ivx};   // d alpha / d(vx, vy, r)
   // second derivatives of alpha: (vx,vx), (vx,vy), (vx,r); all others zero
@@ -141,10 +143,11 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   const int N = c.N, lane = wv::lane(), k = lane;
   const int nz = a.nz, nobs = c.n_obs;
   if (RESTO && a.status[(size_t)b * a.st_stride] != MPCB_ST_NEEDS_RESTO) return;     // wave-uniform: this instance is done
-  const LayoutDyn L = layout_dyn(N, RESTO);
+  constexpr bool OBL = NOBS > 3;                  // obstacle constants in LDS instead of registers (see mpcb_solve_kin)
+  const LayoutDyn L = layout_dyn(N, RESTO, obs_in_lds(NOBS));
   const int ld = L.ld;
   double* ent = lds + L.ent;
-  const double T = c.T;
+  const double T = a.tgrid ? a.tgrid[k < N ? k : N - 1] : c.T;     // step length of this lane's stage (time grid or cfg.T)
 
   const bool isnode = k <= N, hasu = k < N, xnode = k >= 1 && k <= N, xcost = k >= 1 && k < N;
   const double* gx0 = a.x0 + (size_t)b * NX;
@@ -158,22 +161,31 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   if (c.obs_mode == MPCB_OBS_KEEPOUT) { obs_node = k <= last_row; ostep = k; }
   else { obs_node = k >= 1 && k - 1 <= last_row; ostep = k - 1; }
   obs_node = obs_node && isnode;
-  double ox[NOB], oy[NOB], ix2[NOB], iy2[NOB];
+  double ox_[OBL ? 1 : NOB], oy_[OBL ? 1 : NOB], ix2_[OBL ? 1 : NOB], iy2_[OBL ? 1 : NOB];
+  double* obl = lds + L.obl;
+  auto OC = [&](int j, int q) -> double& {
+    if constexpr (OBL) return obl[(4 * j + q) * 64 + lane];
+    else return q == 0 ? ox_[j] : q == 1 ? oy_[j] : q == 2 ? ix2_[j] : iy2_[j];
+  };
+#define ox(j) OC(j, 0)
+#define oy(j) OC(j, 1)
+#define ix2(j) OC(j, 2)
+#define iy2(j) OC(j, 3)
 #pragma unroll
   for (int j = 0; j < NOBS; ++j) {
-    ox[j] = 0; oy[j] = 0; ix2[j] = 0; iy2[j] = 0;
+    ox(j) = 0; oy(j) = 0; ix2(j) = 0; iy2(j) = 0;
     if (j < nobs && obs_node) {
       const double* q = (a.obs_kind == MPCB_OBSIN_PREDICTED)
                             ? a.obs + (((size_t)b * nobs + j) * (N + 1) + ostep) * 6
                             : a.obs + ((size_t)b * nobs + j) * 6;
       double sx = c.obs_sx_fixed > 0 ? c.obs_sx_fixed : c.ego_hl + q[4] / 2 + c.safe_disl;
       double sy = c.obs_sy_fixed > 0 ? c.obs_sy_fixed : c.ego_hw + q[5] / 2 + c.safe_disw;
-      ox[j] = q[0]; oy[j] = q[1]; ix2[j] = 1.0 / (sx * sx); iy2[j] = 1.0 / (sy * sy);
+      ox(j) = q[0]; oy(j) = q[1]; ix2(j) = 1.0 / (sx * sx); iy2(j) = 1.0 / (sy * sy);
     }
   }
   auto hval = [&](int j, double px, double py) {
-    double dx = px - ox[j], dy = py - oy[j];
-    return dx * dx * ix2[j] + dy * dy * iy2[j] - 1.0;
+    double dx = px - ox(j), dy = py - oy(j);
+    return dx * dx * ix2(j) + dy * dy * iy2(j) - 1.0;
   };
 
   double* zbuf = lds + L.zbuf;
@@ -297,7 +309,8 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   const Bnd qU0 = mk_bnd(c.u_lo[0], c.u_hi[0], c.bound_relax), qU1 = mk_bnd(c.u_lo[1], c.u_hi[1], c.bound_relax);
   const Bnd qY = mk_bnd(c.x_lo[1], c.x_hi[1], c.bound_relax), qVx = mk_bnd(c.x_lo[3], c.x_hi[3], c.bound_relax);
   const Bnd qVy = mk_bnd(c.x_lo[4], c.x_hi[4], c.bound_relax);
-  const Bnd qR0 = mk_bnd(c.du_lo[0], c.du_hi[0], c.bound_relax), qR1 = mk_bnd(c.du_lo[1], c.du_hi[1], c.bound_relax);
+  const double rsc = a.tgrid ? wv::shfl(T, k - 1) / c.T : 1.0;    // rate rows: bounds scale with the time between the two controls
+  const Bnd qR0 = mk_bnd_lane(c.du_lo[0] * rsc, c.du_hi[0] * rsc, c.bound_relax), qR1 = mk_bnd_lane(c.du_lo[1] * rsc, c.du_hi[1] * rsc, c.bound_relax);
   const Bnd qO = mk_bnd(c.obs_hmin, 1e308, c.bound_relax);
   const bool bu0_on = hasu && qU0.on, bu1_on = hasu && qU1.on;
   const bool by_on = xnode && qY.on, bvx_on = xnode && qVx.on, bvy_on = xnode && qVy.on;
@@ -315,7 +328,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       for (int i = 0; i < NX; ++i) Xs[i] = X[i];
       if (!okx) Xs[3] = 1e-3;
       DynEval e; dyn_eval(c, Xs, U, e);
-      double F[NX]; dyn_F(c, Xs, U, e, F);
+      double F[NX]; dyn_F(c, T, Xs, U, e, F);
 #pragma unroll
       for (int i = 0; i < NX; ++i) { const double n = wv::bcast(F[i], s); if (k == s + 1) X[i] = n; }
     }
@@ -363,7 +376,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   auto eval_lane = [&](const double* Xa, const double* Ua, double sR0a, double sR1a, const double* sOa, const double* pa, const double* na, const DynEval& e,
                        double* dfa, double& rR0a, double& rR1a, double* rOa, double& up0, double& up1, double& th, double& fl, double& prod) {
     bool ok = true;
-    double Ft[NX]; dyn_F(c, Xa, Ua, e, Ft);
+    double Ft[NX]; dyn_F(c, T, Xa, Ua, e, Ft);
     th = 0; fl = 0; prod = 1.0;
 #pragma unroll
     for (int i = 0; i < NX; ++i) { const double xn = wv::shfl(Xa[i], k + 1); dfa[i] = hasu ? Ft[i] - xn : 0.0; th += fabs(dfa[i]); }
@@ -506,7 +519,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
 
   if (status != MPCB_ST_INFEASIBLE_X0) {
 #pragma unroll
-    for (int j = 0; j < NOBS; ++j) if (ro_on[j]) { gO0[j] = 2 * (X[0] - ox[j]) * ix2[j]; gO1[j] = 2 * (X[1] - oy[j]) * iy2[j]; }
+    for (int j = 0; j < NOBS; ++j) if (ro_on[j]) { gO0[j] = 2 * (X[0] - ox(j)) * ix2(j); gO1[j] = 2 * (X[1] - oy(j)) * iy2(j); }
     if (!RESTO) {
       DynEval ev; dyn_eval(c, X, U, ev);
       double th, fl, prod;
@@ -589,7 +602,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       MPCB_STAMP(t_a);
       // tyre forces and trig at the iterate are recomputed here rather than kept across the line search (13 doubles/lane)
       DynEval ev; dyn_eval(c, X, U, ev);
-      DynJac J; dyn_jac(c, X, ev, J);
+      DynJac J; dyn_jac(c, T, X, ev, J);
       recips();
       double ln[NX];
 #pragma unroll
@@ -799,7 +812,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
             hd[8] += w0; hd[6] += w0; h68 -= w0; hd[9] += w1; hd[7] += w1; h79 -= w1;
             g[8] += w0 * d0; g[6] -= w0 * d0; g[9] += w1 * d1; g[7] -= w1 * d1;
           }
-          dyn_hess(c, X, ev, ln, Hh);
+          dyn_hess(c, T, X, ev, ln, Hh);
           hd[2] += Hh.h22; hd[3] += Hh.h33; hd[4] += Hh.h44; hd[5] += Hh.h55; hd[8] += Hh.h88;
         }
         double sig, gb;
@@ -819,9 +832,9 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
             const double rt = rO[j] + (RS_RHO + gb - mu / eP[j]) * isp + (gb - RS_RHO + mu / eN[j]) * isn;
             sig *= kap; gb -= sig * rt;
           } else gb -= sig * rO[j];
-          hd[0] += sig * gO0[j] * gO0[j] - vO[j] * 2 * ix2[j];
+          hd[0] += sig * gO0[j] * gO0[j] - vO[j] * 2 * ix2(j);
           h01 += sig * gO0[j] * gO1[j];
-          hd[1] += sig * gO1[j] * gO1[j] - vO[j] * 2 * iy2[j];
+          hd[1] += sig * gO1[j] * gO1[j] - vO[j] * 2 * iy2(j);
           g[0] -= gb * gO0[j]; g[1] -= gb * gO1[j];
         }
         if (isnode) {
@@ -843,6 +856,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           fk[DFW_B] = z * J.b4; fk[DFW_B + 1] = z * J.b5;
 #pragma unroll
           for (int i = 0; i < NX; ++i) fk[DFW_D + i] = dfc[i];
+          fk[DFW_T] = T;
           pst[k * DPSS + 8] = 0.0;
           ent[DE_H01 * ld + k] = h01; ent[DE_H23 * ld + k] = Hh.h23; ent[DE_H24 * ld + k] = Hh.h24;
           ent[DE_H34 * ld + k] = Hh.h34; ent[DE_H35 * ld + k] = Hh.h35; ent[DE_H45 * ld + k] = Hh.h45;
@@ -867,13 +881,13 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         Pst[N * DPST + ei * NA + ej] = ent[sHij + N];
         if (ej == 0) pst[N * DPSS + ei] = ent[(DE_G0 + ei) * ld + N];
         wv::sync();
-        struct StageEnt { double abj[NX], abi[NX], start, hmat, startU, hU, startUU, b4, b5; };
+        struct StageEnt { double abj[NX], abi[NX], start, hmat, startU, hU, startUU, b4, b5, Ts; };
         auto load_ent = [&](int s, StageEnt& e) {
 #pragma unroll
           for (int r = 0; r < NX; ++r) { e.abj[r] = ent[sABj[r] + s]; e.abi[r] = ent[sABi[r] + s]; }
           e.start = ent[sStart + s]; e.hmat = ent[sHij + s];
           e.startU = ent[sStartU + s]; e.hU = ent[sHU + s]; e.startUU = ent[sStartUU + s];
-          e.b4 = ent[DE_B4 * ld + s]; e.b5 = ent[DE_B5 * ld + s];
+          e.b4 = ent[DE_B4 * ld + s]; e.b5 = ent[DE_B5 * ld + s]; e.Ts = ent[DE_T * ld + s];
         };
         auto stage = [&](int s) -> bool {
           StageEnt e; load_ent(s, e);
@@ -886,7 +900,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           // W_x = P+ [A | d] over the state columns (rows 6,7 of [A B] are zero), W_u = P+ B over the two control columns
           const double w = fma(Pr[4], e.abj[4], fma(Pr[2], e.abj[2], fma(Pr[0], e.abj[0], w0))) +
                            fma(Pr[5], e.abj[5], fma(Pr[3], e.abj[3], Pr[1] * e.abj[1]));
-          const double wu = (ej & 1) ? fma(T, Pr[3], Pr[7]) : fma(e.b4, Pr[4], fma(e.b5, Pr[5], Pr[6]));
+          const double wu = (ej & 1) ? fma(e.Ts, Pr[3], Pr[7]) : fma(e.b4, Pr[4], fma(e.b5, Pr[5], Pr[6]));
           Wl[ej * NA + ei] = w;
           WuL[wuOff] = wu;
           wv::sync();
@@ -899,8 +913,8 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           // M_xx = H_xx + A^T W_x  (affine lanes: m_x);  M_ux(c,:) = H_ux + B_c^T W_x (affine lanes: m_u);  M_uu = H_uu + B^T W_u
           const double acc = fma(e.abi[4], Wc[4], fma(e.abi[2], Wc[2], fma(e.abi[0], Wc[0], e.start))) +
                              fma(e.abi[5], Wc[5], fma(e.abi[3], Wc[3], e.abi[1] * Wc[1]));
-          const double mux = e.startU + (cU ? fma(T, Wc[3], Wc[7]) : fma(e.b4, Wc[4], fma(e.b5, Wc[5], Wc[6])));
-          const double muu = e.startUU + (cU ? fma(T, Wuc[3], Wuc[7]) : fma(e.b4, Wuc[4], fma(e.b5, Wuc[5], Wuc[6])));
+          const double mux = e.startU + (cU ? fma(e.Ts, Wc[3], Wc[7]) : fma(e.b4, Wc[4], fma(e.b5, Wc[5], Wc[6])));
+          const double muu = e.startUU + (cU ? fma(e.Ts, Wuc[3], Wuc[7]) : fma(e.b4, Wuc[4], fma(e.b5, Wuc[5], Wuc[6])));
           const double Mx = aff ? e.hmat : acc;
           const double MxU = aff ? e.hU : mux;
           const double m11 = wv::bcast(muu, 48), m12 = wv::bcast(muu, 49), m22 = wv::bcast(muu, 57);
@@ -939,7 +953,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       // ----- forward roll-out of the step (per-stage numbers contiguous in fw, prefetched one stage ahead) -----------
       double dX[NX] = {0, 0, 0, 0, 0, 0}, dU[NU] = {0, 0};
       {
-        struct FwEnt { double K[2 * NA], kf0, kf1, a[14], b4, b5, d[NX]; };
+        struct FwEnt { double K[2 * NA], kf0, kf1, a[14], b4, b5, d[NX], Ts; };
         auto load_fw = [&](int s, FwEnt& f) {
           const double* q = fw + s * DFWS;
 #pragma unroll
@@ -950,6 +964,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           f.b4 = q[DFW_B]; f.b5 = q[DFW_B + 1];
 #pragma unroll
           for (int r = 0; r < NX; ++r) f.d[r] = q[DFW_D + r];
+          f.Ts = q[DFW_T];
         };
         double dx[NA] = {0, 0, 0, 0, 0, 0, 0, 0};
         auto fstage = [&](int s, const FwEnt& f) {
@@ -961,8 +976,8 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           // a[] = {a02,a03,a04, a12,a13,a14, a34,a35, a43,a44,a45, a53,a54,a55}
           const double n0 = dx[0] + f.a[0] * dx[2] + f.a[1] * dx[3] + f.a[2] * dx[4] + f.d[0];
           const double n1 = dx[1] + f.a[3] * dx[2] + f.a[4] * dx[3] + f.a[5] * dx[4] + f.d[1];
-          const double n2 = dx[2] + T * dx[5] + f.d[2];
-          const double n3 = dx[3] + f.a[6] * dx[4] + f.a[7] * dx[5] + T * du1 + f.d[3];
+          const double n2 = dx[2] + f.Ts * dx[5] + f.d[2];
+          const double n3 = dx[3] + f.a[6] * dx[4] + f.a[7] * dx[5] + f.Ts * du1 + f.d[3];
           const double n4 = f.a[8] * dx[3] + f.a[9] * dx[4] + f.a[10] * dx[5] + f.b4 * du0 + f.d[4];
           const double n5 = f.a[11] * dx[3] + f.a[12] * dx[4] + f.a[13] * dx[5] + f.b5 * du0 + f.d[5];
           if (k == s) { dU[0] = du0; dU[1] = du1; }
@@ -1171,7 +1186,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
 #pragma unroll
       for (int j = 0; j < NOBS; ++j) {
         sO[j] = sOt[j]; rO[j] = rOt[j];
-        if (ro_on[j]) { gO0[j] = 2 * (X[0] - ox[j]) * ix2[j]; gO1[j] = 2 * (X[1] - oy[j]) * iy2[j]; }
+        if (ro_on[j]) { gO0[j] = 2 * (X[0] - ox(j)) * ix2(j); gO1[j] = 2 * (X[1] - oy(j)) * iy2(j); }
       }
       theta = tht; fval = ft; logsum = lst;
       if (!isfinite(theta) || !isfinite(fval)) { status = MPCB_ST_NUMERIC; break; }
@@ -1257,7 +1272,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       for (int i = 0; i < NX; ++i) Xs[i] = X[i];
       if (!(Xs[3] > 1e-3)) Xs[3] = 1e-3;
       DynEval ev; dyn_eval(c, Xs, U, ev);
-      DynJac J; dyn_jac(c, Xs, ev, J);
+      DynJac J; dyn_jac(c, T, Xs, ev, J);
       const double At[NX] = {ln[0], ln[1], J.a02 * ln[0] + J.a12 * ln[1] + ln[2],
                              J.a03 * ln[0] + J.a13 * ln[1] + ln[3] + J.a43 * ln[4] + J.a53 * ln[5],
                              J.a04 * ln[0] + J.a14 * ln[1] + J.a34 * ln[3] + J.a44 * ln[4] + J.a54 * ln[5],
@@ -1277,3 +1292,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
     }
   }
 }
+#undef ox
+#undef oy
+#undef ix2
+#undef iy2

@@ -113,6 +113,14 @@ class BatchSolver:
             raise ValueError("lbx/ubx or lbg/ubg lengths differ")
         check(lib().mpcb_set_bounds(self._h, dptr(lbx), dptr(ubx), lbx.size, dptr(lbg), dptr(ubg), lbg.size), self._h)
 
+    def set_time_grid(self, T_i=None):
+        """Step length of every stage (N values), or None for cfg.T everywhere (the reference's behaviour)."""
+        if T_i is None:
+            check(lib().mpcb_set_time_grid(self._h, None, 0), self._h)
+        else:
+            t = np.ascontiguousarray(T_i, dtype=np.float64).reshape(-1)
+            check(lib().mpcb_set_time_grid(self._h, dptr(t), t.size), self._h)
+
     def _obs(self, obs, B):
         if self.cfg.n_obs == 0:
             return None, _abi.OBSIN_STATIC

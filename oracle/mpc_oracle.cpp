@@ -167,7 +167,7 @@ struct ModelEval {
 };
 
 // F, A, B and (optionally) Hc = sum_a lam[a] * d2F_a/d[X,U]^2 by AD
-void model_eval_ad(const mpcb_config& c, const double* X, const double* U, const double* lam, ModelEval& me,
+void model_eval_ad(const mpcb_config& c, double T, const double* X, const double* U, const double* lam, ModelEval& me,
                    double Hc[NVM][NVM]) {
   const int nx = nx_of(c);
   typedef D2<NVM> S;
@@ -176,22 +176,22 @@ void model_eval_ad(const mpcb_config& c, const double* X, const double* U, const
   for (int i = 0; i < NU; ++i) u[i] = S::var(U[i], nx + i);
   if (c.model == MPCB_MODEL_DYN) rhs_dyn<S>(c, x, u, o); else rhs_kin<S>(c, x, u, o);
   for (int a = 0; a < nx; ++a) {
-    me.F[a] = X[a] + c.T * o[a].v;
-    for (int j = 0; j < nx; ++j) me.A[a][j] = (a == j ? 1.0 : 0.0) + c.T * o[a].g[j];
-    for (int j = 0; j < NU; ++j) me.B[a][j] = c.T * o[a].g[nx + j];
+    me.F[a] = X[a] + T * o[a].v;
+    for (int j = 0; j < nx; ++j) me.A[a][j] = (a == j ? 1.0 : 0.0) + T * o[a].g[j];
+    for (int j = 0; j < NU; ++j) me.B[a][j] = T * o[a].g[nx + j];
   }
   if (Hc) {
     for (int i = 0; i < NVM; ++i) for (int j = 0; j < NVM; ++j) Hc[i][j] = 0.0;
     if (lam)
       for (int a = 0; a < nx; ++a)
-        for (int i = 0; i < nx + NU; ++i) for (int j = 0; j < nx + NU; ++j) Hc[i][j] += lam[a] * c.T * o[a].h[i][j];
+        for (int i = 0; i < nx + NU; ++i) for (int j = 0; j < nx + NU; ++j) Hc[i][j] += lam[a] * T * o[a].h[i][j];
   }
 }
 
 // hand-written kinematic derivatives (what the HIP kernel also codes); checked against AD in tests
-void model_eval_kin(const mpcb_config& c, const double* X, const double* U, const double* lam, ModelEval& me,
+void model_eval_kin(const mpcb_config& c, double T, const double* X, const double* U, const double* lam, ModelEval& me,
                     double Hc[NVM][NVM]) {
-  const double T = c.T, il = 1.0 / c.veh_l;
+  const double il = 1.0 / c.veh_l;
   const double phi = X[2], v = X[3], df = U[0], a = U[1];
   const double sp = std::sin(phi), cp = std::cos(phi), td = std::tan(df), sec2 = 1.0 + td * td;
   me.F[0] = X[0] + T * v * cp;
@@ -217,10 +217,11 @@ void model_eval_kin(const mpcb_config& c, const double* X, const double* U, cons
   }
 }
 
-void model_eval(const mpcb_config& c, const double* X, const double* U, const double* lam, ModelEval& me,
+// T = step length of the stage: cfg.T, or the stage's entry of the time grid (mpcb_set_time_grid)
+void model_eval(const mpcb_config& c, double T, const double* X, const double* U, const double* lam, ModelEval& me,
                 double Hc[NVM][NVM], bool force_ad = false) {
-  if (c.model == MPCB_MODEL_KIN && !force_ad) model_eval_kin(c, X, U, lam, me, Hc);
-  else model_eval_ad(c, X, U, lam, me, Hc);
+  if (c.model == MPCB_MODEL_KIN && !force_ad) model_eval_kin(c, T, X, U, lam, me, Hc);
+  else model_eval_ad(c, T, X, U, lam, me, Hc);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -268,6 +269,7 @@ struct Solver {
   const double *x0, *xs;
   ObsP obs[NODES][NOBM];
   bool obs_node[NODES];
+  double Tk[NODES];                // step length of stage k: cfg.T, or the time grid (the variable-time grid of kin.py:19-25 made effective)
 
   // iterate
   double X[NODES][NXM], U[NODES][NU], lam[NODES][NXM];
@@ -337,7 +339,7 @@ struct Solver {
   bool gen() const { return c.model == MPCB_MODEL_KIN && c.obs_mode == MPCB_OBS_DCBF && c.gamma < 1.0 - 1e-12; }
   template <class S> S crow(int k, int j, const S* x) const {   // x = (x, y, phi, v)
     const ObsP& q = obs[k][j];
-    S qx = x[0] + c.T * (x[3] * cos(x[2])), qy = x[1] + c.T * (x[3] * sin(x[2]));
+    S qx = x[0] + Tk[k] * (x[3] * cos(x[2])), qy = x[1] + Tk[k] * (x[3] * sin(x[2]));
     S a = qx - q.ox, b = qy - q.oy, d = x[0] - q.ox, e = x[1] - q.oy;
     S hq = a * a * q.ix2 + b * b * q.iy2 - 1.0, hp = d * d * q.ix2 + e * e * q.iy2 - 1.0;
     return hq - (1.0 - c.gamma) * hp;
@@ -374,8 +376,9 @@ struct Solver {
 
   // ----- problem set-up ----------------------------------------------------------------------------------
   // obstacles: static [nobs][6] or predicted [nobs][N+1][6]; rows [x,y,theta,v,l,w]
-  bool init(const double* x0_, const double* xs_, const double* ob, int obs_kind, const double* z0) {
+  bool init(const double* x0_, const double* xs_, const double* ob, int obs_kind, const double* z0, const double* tgrid) {
     x0 = x0_; xs = xs_;
+    for (int k = 0; k < NODES; ++k) Tk[k] = tgrid ? tgrid[k < N ? k : N - 1] : c.T;
     const int last_row = c.obs_terminal ? N : N - 1;       // reference row index range 0..last_row
     for (int k = 0; k <= N; ++k) {
       obs_node[k] = false;
@@ -421,7 +424,7 @@ struct Solver {
       for (int k = 0; k < N; ++k) {
         double Uc[NU]; for (int i = 0; i < NU; ++i) Uc[i] = std::min(std::max(U[k][i], c.u_lo[i]), c.u_hi[i]);
         double f[NXM]; rhs_any(c, X[k], Uc, f);
-        for (int i = 0; i < nx; ++i) X[k + 1][i] = X[k][i] + c.T * f[i];
+        for (int i = 0; i < nx; ++i) X[k + 1][i] = X[k][i] + Tk[k] * f[i];
       }
     }
 
@@ -448,7 +451,8 @@ struct Solver {
     // general rows: slack = row value at the pushed start, pushed inside its own bounds
     for (int k = 0; k <= N; ++k) {
       for (int i = 0; i < NU; ++i) {
-        setup(rR[k][i], c.du_lo[i], c.du_hi[i]);
+        const double sc = (k >= 1) ? Tk[k - 1] / c.T : 1.0;        // cfg.du_* are rate * cfg.T (kin.py:116-121); with a time grid: rate * T_{k-1}
+        setup(rR[k][i], c.du_lo[i] * sc, c.du_hi[i] * sc);
         Ineq& it = rR[k][i]; it.on = it.on && k >= 1 && k < N; if (!it.on) continue;
         relax(c, it); it.s = push(it, U[k][i] - U[k - 1][i]); it.vL = it.vU = 1.0;
         it.i0 = na + i; it.g0 = 1.0; it.i1 = nx + i; it.g1 = -1.0;
@@ -513,7 +517,7 @@ struct Solver {
   void eval_point() {
     theta = 0;
     for (int k = 0; k < N; ++k) {
-      model_eval(c, X[k], U[k], nullptr, me[k], nullptr); ++n_dyn_eval;
+      model_eval(c, Tk[k], X[k], U[k], nullptr, me[k], nullptr); ++n_dyn_eval;
       for (int i = 0; i < nx; ++i) { dfc[k][i] = me[k].F[i] - X[k + 1][i]; theta += std::fabs(dfc[k][i]); }
     }
     for (int k = 0; k <= N; ++k) {
@@ -604,7 +608,7 @@ struct Solver {
       }
       double Hc[NVM][NVM];
       ModelEval tmp;
-      model_eval(c, X[k], U[k], lam[k + 1], tmp, Hc);
+      model_eval(c, Tk[k], X[k], U[k], lam[k + 1], tmp, Hc);
       auto map = [&](int i) { return i < nx ? i : na + (i - nx); };
       for (int i = 0; i < nx + NU; ++i) for (int j = 0; j < nx + NU; ++j) Hk[map(i)][map(j)] += Hc[i][j];
     }
@@ -774,7 +778,7 @@ struct Solver {
     }
     for (int k = 0; k < N; ++k) {
       double f[NXM]; rhs_any(c, Xt[k], Ut[k], f); ++n_dyn_eval;
-      for (int i = 0; i < nx; ++i) t.theta += std::fabs(Xt[k][i] + c.T * f[i] - Xt[k + 1][i]);
+      for (int i = 0; i < nx; ++i) t.theta += std::fabs(Xt[k][i] + Tk[k] * f[i] - Xt[k + 1][i]);
     }
     t.f = objective(Xt, Ut);
     double phi = osc * t.f;
@@ -1240,7 +1244,7 @@ int mpco_model_rhs(const mpcb_config* cfg, const double* x, const double* u, dou
 // Oracle batch solve: same arrays as mpcb_solve.  threads <= 0: all OpenMP threads.
 int mpco_solve(const mpcb_config* cfg, int32_t B, const double* x0, const double* xs, const double* obs,
                int32_t obs_kind, const double* z0, double* z, double* obj, int32_t* status, int32_t* iters,
-               double* kkt, double* lam_g, double* lam_x, int32_t threads) {
+               double* kkt, double* lam_g, double* lam_x, int32_t threads, const double* tgrid) {
   int rc = check_cfg(cfg);
   if (rc != MPCB_OK) return rc;
   if (B < 0 || !x0 || !xs || !z || (cfg->n_obs > 0 && !obs)) return MPCB_E_INVALID;
@@ -1256,7 +1260,7 @@ int mpco_solve(const mpcb_config* cfg, int32_t B, const double* x0, const double
     if (!arena) arena = ::operator new(sizeof(Solver));
     Solver* s = new (arena) Solver(*cfg);
     bool ok = s->init(x0 + (size_t)b * nx, xs + (size_t)b * nx, obs ? obs + b * obs_stride : nullptr, obs_kind,
-                      z0 ? z0 + (size_t)b * nz : nullptr);
+                      z0 ? z0 + (size_t)b * nz : nullptr, tgrid);
     if (ok) s->solve(); else s->eval_point();
     s->write(z + (size_t)b * nz, obj ? obj + b : nullptr, status ? status + b : nullptr, iters ? iters + b : nullptr,
              kkt ? kkt + (size_t)b * 4 : nullptr, lam_g ? lam_g + (size_t)b * ng : nullptr,
@@ -1272,7 +1276,7 @@ int mpco_model_eval(const mpcb_config* cfg, const double* X, const double* U, co
   if (check_cfg(cfg) != MPCB_OK) return MPCB_E_INVALID;
   const int nx = nx_of(*cfg);
   ModelEval me; double H[NVM][NVM];
-  model_eval(*cfg, X, U, lam, me, H, ad != 0);
+  model_eval(*cfg, cfg->T, X, U, lam, me, H, ad != 0);
   for (int i = 0; i < nx; ++i) {
     F[i] = me.F[i];
     for (int j = 0; j < nx; ++j) A[i * nx + j] = me.A[i][j];

@@ -50,7 +50,7 @@ def dims(cfg):
     return nx.value, nz.value, ng.value
 
 
-def solve(cfg, x0, xs, obs=None, z0=None, threads=0, want_multipliers=True):
+def solve(cfg, x0, xs, obs=None, z0=None, threads=0, want_multipliers=True, tgrid=None):
     """Returns dict(z, obj, status, iters, kkt, lam_g, lam_x); arrays are [B, ...]."""
     x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
     xs = np.ascontiguousarray(np.atleast_2d(xs), dtype=np.float64)
@@ -69,13 +69,17 @@ def solve(cfg, x0, xs, obs=None, z0=None, threads=0, want_multipliers=True):
         obs = None
     if z0 is not None:
         z0 = np.ascontiguousarray(z0, dtype=np.float64).reshape(B, nz)
+    tg = None
+    if tgrid is not None:
+        tg = np.ascontiguousarray(tgrid, dtype=np.float64).reshape(-1)
+        assert tg.size == cfg.N, "the time grid has one step length per stage"
     z = np.zeros((B, nz)); obj = np.zeros(B); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32)
     kkt = np.zeros((B, 4))
     lam_g = np.zeros((B, ng)) if want_multipliers else None
     lam_x = np.zeros((B, nz)) if want_multipliers else None
     rc = lib().mpco_solve(C.byref(cfg), C.c_int32(B), dptr(x0), dptr(xs), dptr(obs), C.c_int32(kind), dptr(z0),
                           dptr(z), dptr(obj), iptr(st), iptr(it), dptr(kkt), dptr(lam_g), dptr(lam_x),
-                          C.c_int32(threads))
+                          C.c_int32(threads), dptr(tg))
     if rc != 0:
         raise RuntimeError("mpco_solve failed with code %d" % rc)
     return dict(z=z, obj=obj, status=st, iters=it, kkt=kkt, lam_g=lam_g, lam_x=lam_x)

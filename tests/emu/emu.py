@@ -20,7 +20,7 @@ def lib():
     return _LIB
 
 
-def solve(cfg, x0, xs, obs=None, z0=None, trace_instance=-1):
+def solve(cfg, x0, xs, obs=None, z0=None, trace_instance=-1, tgrid=None):
     x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
     xs = np.ascontiguousarray(np.atleast_2d(xs), dtype=np.float64)
     B = x0.shape[0]; N = cfg.N; nx = cfg.nx()
@@ -41,7 +41,7 @@ def solve(cfg, x0, xs, obs=None, z0=None, trace_instance=-1):
     trace = np.zeros((cfg.max_iter + 1, 8)) if trace_instance >= 0 else None
     rc = lib().mpcb_emu_solve(C.byref(cfg), C.c_int32(B), dptr(x0), dptr(xs), dptr(obs), C.c_int32(kind), dptr(z0),
                               dptr(z), dptr(obj), iptr(st), iptr(it), dptr(kkt), dptr(lam_g), dptr(lam_x),
-                              dptr(trace), C.c_int32(trace_instance))
+                              dptr(trace), C.c_int32(trace_instance), dptr(None if tgrid is None else np.ascontiguousarray(tgrid, dtype=np.float64)))
     if rc != 0:
         raise RuntimeError("mpcb_emu_solve failed with code %d" % rc)
     return dict(z=z, obj=obj, status=st, iters=it, kkt=kkt, lam_g=lam_g, lam_x=lam_x, trace=trace)

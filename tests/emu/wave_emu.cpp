@@ -21,7 +21,7 @@ static void run_instance(const MpcbKArgs& a, int b) {
   using namespace mpcbk;
   const bool dyn = a.cfg.model == MPCB_MODEL_DYN;
   const bool rp = a.pass == 1;                                    // restoration pass: the RESTO instantiations
-  const int total = dyn ? layout_dyn(a.cfg.N, rp).total : layout_kin(a.cfg.N, a.nz, rp).total;
+  const int total = dyn ? layout_dyn(a.cfg.N, rp, obs_in_lds(NOBS)).total : layout_kin(a.cfg.N, a.nz, rp, obs_in_lds(NOBS)).total;
   std::vector<double> lds(total + 64, 0.0);
   std::barrier<> bar(64);
   wv::Emu emu; emu.bar = &bar;
@@ -42,7 +42,7 @@ static void run_instance(const MpcbKArgs& a, int b) {
 
 extern "C" int mpcb_emu_solve(const mpcb_config* cfg, int32_t B, const double* x0, const double* xs, const double* obs,
                               int32_t obs_kind, const double* z0, double* z, double* obj, int32_t* status, int32_t* iters,
-                              double* kkt, double* lam_g, double* lam_x, double* trace, int32_t trace_instance) {
+                              double* kkt, double* lam_g, double* lam_x, double* trace, int32_t trace_instance, const double* tgrid) {
   if (!cfg) return MPCB_E_INVALID;
   const int nx = cfg->model == MPCB_MODEL_DYN ? 6 : 4;
   int nrate = 0;
@@ -53,7 +53,7 @@ extern "C" int mpcb_emu_solve(const mpcb_config* cfg, int32_t B, const double* x
   a.nz = 2 * cfg->N + nx * (cfg->N + 1);
   a.ng = nx * (cfg->N + 1) + nrate * (cfg->N - 1) + cfg->n_obs * (cfg->obs_terminal ? cfg->N + 1 : cfg->N);
   a.x0 = x0; a.xs = xs; a.obs = obs; a.z0 = z0; a.z = z; a.obj = obj; a.kkt = kkt; a.lam_g = lam_g; a.lam_x = lam_x;
-  a.status = status; a.iters = iters; a.trace = trace;
+  a.status = status; a.iters = iters; a.trace = trace; a.tgrid = tgrid;
   std::vector<double> work((size_t)B * mpcbk::WK_SIZE, 0.0);
   const bool two_pass = cfg->restoration != 0;                                 // as mpcb_api.hip: first pass, then the restoration pass
   a.work = two_pass ? work.data() : nullptr;
@@ -76,11 +76,11 @@ extern "C" int mpcb_emu_dyn_model(const mpcb_config* cfg, const double* X, const
                                   double* hess13) {
   using namespace mpcbk;
   DynEval e; dyn_eval(*cfg, X, U, e);
-  dyn_F(*cfg, X, U, e, F);
-  DynJac J; dyn_jac(*cfg, X, e, J);
+  dyn_F(*cfg, cfg->T, X, U, e, F);
+  DynJac J; dyn_jac(*cfg, cfg->T, X, e, J);
   const double j[16] = {J.a02, J.a03, J.a04, J.a12, J.a13, J.a14, J.a34, J.a35, J.a43, J.a44, J.a45, J.a53, J.a54, J.a55, J.b4, J.b5};
   for (int i = 0; i < 16; ++i) jac16[i] = j[i];
-  DynHess H; dyn_hess(*cfg, X, e, lam, H);
+  DynHess H; dyn_hess(*cfg, cfg->T, X, e, lam, H);
   const double h[13] = {H.h22, H.h23, H.h24, H.h33, H.h34, H.h35, H.h44, H.h45, H.h55, H.h38, H.h48, H.h58, H.h88};
   for (int i = 0; i < 13; ++i) hess13[i] = h[i];
   return 0;

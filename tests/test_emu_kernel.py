@@ -98,3 +98,21 @@ def test_emulated_kernel_end_game_needs_symmetric_p():
     e = emu.solve(cfg, d["x0"], d["xs"], d["obs"]); r = oracle.solve(cfg, d["x0"], d["xs"], d["obs"])
     assert np.all(r["status"] == 0) and np.all(e["status"] == 0)
     assert np.abs(e["iters"] - r["iters"]).max() <= 4 and np.abs(e["z"] - r["z"]).max() <= 1e-5
+
+
+def test_emulated_kernels_with_a_time_grid():
+    """Per-stage step lengths (mpcb_set_time_grid; the two-rate grid of kin.py:19-25 made effective) through the kernel source
+    and the oracle: same status, same iteration count, same point; the shooting rows hold with T_i and the rate rows with
+    rate * T_{i-1}."""
+    c = product_cfg()
+    tg = np.concatenate([np.full(24, 0.1), np.full(6, 0.5)])
+    x0, xs, obs = scenes.sample_c2(3, seed=3)
+    r = oracle.solve(c, x0, xs, obs, tgrid=tg); e = emu.solve(c, x0, xs, obs, tgrid=tg)
+    assert np.array_equal(r["status"], e["status"]) and np.array_equal(r["iters"], e["iters"]) and r["status"][0] == 0
+    assert np.abs(r["z"] - e["z"]).max() <= 1e-9
+    z = e["z"][0]; X = z[60:].reshape(31, 4); U = z[:60].reshape(30, 2)
+    f = np.stack([X[:-1, 3] * np.cos(X[:-1, 2]), X[:-1, 3] * np.sin(X[:-1, 2]), X[:-1, 3] * np.tan(U[:, 0]) / 2.6, U[:, 1]], 1)
+    assert np.abs(X[1:] - (X[:-1] + tg[:, None] * f)).max() <= 1e-8
+    assert (np.abs(np.diff(U[:, 0])) - 1e-8).max() <= (5 * np.pi / 180 * tg[:-1]).max() and ((np.abs(np.diff(U[:, 0])) - 2e-8) / tg[:-1]).max() <= 5 * np.pi / 180
+    u = oracle.solve(c, x0, xs, obs); g = oracle.solve(c, x0, xs, obs, tgrid=np.full(30, 0.1))
+    assert np.array_equal(u["z"], g["z"])                              # a grid of T_S everywhere is the fixed grid, bit for bit

@@ -585,3 +585,57 @@ def test_bench_runs_its_multi_rank_plumbing_without_torch():
     import json
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["config"]["value_without_gather"] > 0 and line["value"] > 0 and "RCCL" in line["config"]["collective"]
+
+
+def test_variable_time_grid_on_device(gpu_solver_factory, oracle_mod, tmp_path, monkeypatch):
+    """f4: per-stage step lengths in both kernels (mpcb_set_time_grid).  The drop-in class with `is_variable_time: true`
+    (two-rate grid of kin.py:19-25, N_p = 30) and time_grid_in_nlp = True against the oracle; batches of both models against
+    the oracle; the device closed loop under a grid replayed from the host; a grid of T_S everywhere equals no grid."""
+    from mpc_motion_planning_amd import MPC_CBF_optimize_kin
+    src = os.path.join(os.path.dirname(__file__), "..", "mpc_motion_planning_amd", "sim", "mpc_parameters.yaml")
+    (tmp_path / "mpc_parameters.yaml").write_text(open(src).read().replace("is_variable_time: Flase", "is_variable_time: true"))
+    monkeypatch.chdir(tmp_path)
+    m = MPC_CBF_optimize_kin.MPC_optimize()
+    assert m.N_p == 30
+    x0 = np.array([0, 3, 0, 15.0]).reshape(-1, 1); xs = np.array([400, 3.5, 0, 30.0]).reshape(-1, 1)
+    obs = np.array([[50, 3.5, 0, 8, 4.8, 1.8]])
+    lbg, ubg, lbx, ubx = m.initialize_constraints(obs)
+    cfg = default_config(N=30, n_obs=1)
+    for use_grid in (False, True):
+        m.time_grid_in_nlp = use_grid
+        solver = m.optimize_problem(ego_state=x0, ref_state=None, obstacle=obs)
+        res = solver(x0=np.zeros((184, 1)), p=np.concatenate((x0, xs)), lbg=lbg, lbx=lbx, ubg=ubg, ubx=ubx)
+        ref = oracle_mod.solve(cfg, x0.T, xs.T, obs[None], tgrid=m.stage_lengths() if use_grid else None)
+        assert solver.stats()["success"] and np.abs(res["x"].full()[:, 0] - ref["z"][0]).max() <= TOL_Z
+    assert np.abs(ref["z"][0] - G["S_z"][0]).max() > 1e-2                      # the grid changes the problem (25 x 0.1 s + 5 x 0.5 s)
+    tg = m.stage_lengths()
+    x0b, xsb, obsb = scenes.sample_c2(256, seed=8)
+    bs = gpu_solver_factory(cfg); bs.set_time_grid(tg)
+    g = bs.solve_batch(x0b, xsb, obsb); r = oracle_mod.solve(cfg, x0b, xsb, obsb, tgrid=tg)
+    agree(g, r, min_same_status=0.98)
+    bs.set_time_grid(np.full(30, 0.1)); u = bs.solve_batch(x0b[:32], xsb[:32], obsb[:32])
+    bs.set_time_grid(None); v = bs.solve_batch(x0b[:32], xsb[:32], obsb[:32])
+    assert np.array_equal(u["z"], v["z"]) and np.array_equal(u["iters"], v["iters"])
+    cd = default_config(model=_abi.MODEL_DYN, N=20, n_obs=1)
+    tgd = np.concatenate([np.full(15, 0.1), np.full(5, 0.3)])
+    xd, xsd, od = scenes.sample_c4(128, seed=12, n_obs=1)
+    bd = gpu_solver_factory(cd); bd.set_time_grid(tgd)
+    agree(bd.solve_batch(xd, xsd, od), oracle_mod.solve(cd, xd, xsd, od, tgrid=tgd), tol=TOL_Z_DYN, min_same_status=0.98)
+    # closed loop under the grid: predictions at the grid's node times, plant step T_0 (teacher-forced replay with the same grid)
+    c3 = default_config(N=30, n_obs=2)
+    b3 = gpu_solver_factory(c3); b3.set_time_grid(tg)
+    x0c, xsc, obc, _ = scenes.sample_c3(32, N=30, dt=0.1, seed=77, n_obs=2)
+    dev = b3.closed_loop(x0c, xsc, obc, steps=6, obs_motion=_abi.OBSMOVE_PREDICTED)
+    z0 = np.zeros((32, 184)); oc = obc.copy()
+    for t in range(6):
+        tn = np.concatenate([[0.0], np.cumsum(tg)])                                                    # node times of the grid
+        tr = np.repeat(oc[:, :, None, :], 31, axis=2).copy()
+        tr[..., 0] = oc[:, :, None, 0] + oc[:, :, None, 3] * np.cos(oc[:, :, None, 2]) * tn; tr[..., 1] = oc[:, :, None, 1] + oc[:, :, None, 3] * np.sin(oc[:, :, None, 2]) * tn
+        gq = b3.solve_batch(dev["x_hist"][:, t], xsc, tr, z0=z0)
+        ok = gq["status"] == 0
+        assert (gq["status"] == dev["status"][:, t]).mean() >= 0.9
+        assert np.abs(gq["z"][ok, :2] - dev["u_hist"][ok, t]).max() <= 1e-6                            # (node times: sums vs products round differently)
+        z0 = _shift_plan(np.where(ok[:, None], gq["z"], gq["z"]), 30, 4)
+        oc[:, :, 0] += oc[:, :, 3] * np.cos(oc[:, :, 2]) * tg[0]; oc[:, :, 1] += oc[:, :, 3] * np.sin(oc[:, :, 2]) * tg[0]
+        xn = dev["x_hist"][:, t] + tg[0] * _kin_rhs(dev["x_hist"][:, t], dev["u_hist"][:, t])
+        assert np.abs(xn - dev["x_hist"][:, t + 1]).max() <= 1e-10

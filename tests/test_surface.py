@@ -112,3 +112,19 @@ def test_result_dict_constraint_values_follow_reference_row_order(yaml_horizon3)
     assert c2.obs_mode == _abi.OBS_DCBF and c2.gamma == 0.7
     m.cbf_rows = False
     assert m._make_cfg(2).obs_mode == _abi.OBS_KEEPOUT
+
+
+def test_variable_time_grid_of_the_reference(tmp_path, monkeypatch):
+    """is_variable_time: true -> the reference's two-rate grid (kin.py:19-25): 25 points at T_S = 0.1 up to 2.4 s, then 5 at
+    T_L = 0.5: N_p = 30 for horizon 5, t_ratio 0.5.  stage_lengths() turns it into per-stage step lengths."""
+    import os
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mpc_motion_planning_amd", "sim", "mpc_parameters.yaml")
+    (tmp_path / "mpc_parameters.yaml").write_text(open(src).read().replace("is_variable_time: Flase", "is_variable_time: true"))
+    monkeypatch.chdir(tmp_path)
+    m = MPC_CBF_optimize_kin.MPC_optimize()
+    assert m.is_variable_time is True and m.N_p == 30 and len(m.t_vector) == 30
+    assert m.t_vector[24] == pytest.approx(2.4) and m.t_vector[25] == pytest.approx(2.9) and m.t_vector[-1] == pytest.approx(4.9)
+    T = m.stage_lengths()
+    assert T.shape == (30,) and np.allclose(T[:24], 0.1) and np.allclose(T[24:], 0.5) and m.time_grid_in_nlp is False
+    lbg, ubg, lbx, ubx = m.initialize_constraints(np.array([[50, 3.5, 0, 8, 4.8, 1.8]]))
+    assert len(lbx) == 184 and len(lbg) == 183
