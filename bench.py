@@ -101,7 +101,7 @@ def cpu_baseline_closed_loop(cfg, x0, xs, obs, sim_steps, min_seconds=8.0):
     from oracle import oracle
     from mpc_motion_planning_amd import scenes
     cores = host_cores()
-    n = min(len(x0), 256); N = cfg.N
+    n = min(len(x0), 768); N = cfg.N
     xc = x0[:n].copy(); oc = obs[:n].copy(); z0 = np.zeros((n, 2 * N + 4 * (N + 1)))
     oracle.solve(cfg, xc[:4 * cores], xs[:4 * cores], scenes.predict_obstacles(oc[:4 * cores], cfg.T, N), threads=cores, want_multipliers=False)   # untimed warm-up of the OpenMP team
     t0 = time.perf_counter(); solved = 0; done = 0
@@ -154,13 +154,18 @@ def closed_loop_bench(args, bs, cfg, x0, xs, obs, workload, grp, local_rank):
     H = [bs] + [BatchSolver(cfg, device=local_rank) for _ in range(F - 1)]
     parts = np.array_split(np.arange(len(x0)), F)
     for h_ in H:
-        h_.closed_loop(x0[:256], xs[:256], obs[:256], steps=4, obs_motion=_abi.OBSMOVE_PREDICTED)
+        h_.closed_loop_sampled(_abi.SCENES_C3, 256, 1, steps=4, obs_motion=_abi.OBSMOVE_PREDICTED)
         h_.timing(reset=True)
     res = [None] * F
 
+    seed = 4000                                               # one Monte-Carlo population; rank r draws scenes [r*B, (r+1)*B) of it
+    first = grp.rank * len(x0)
+
     def run(q, hold):
-        res[q] = H[q].closed_loop(x0[parts[q]], xs[parts[q]], obs[parts[q]], steps=sim_steps, obs_motion=_abi.OBSMOVE_PREDICTED,
-                                  hold_on_failure=hold)
+        # scenes are drawn on the device (mpcb_closed_loop_sampled: counter-based generator, global scene index), nothing but the
+        # histories crosses PCIe
+        res[q] = H[q].closed_loop_sampled(_abi.SCENES_C3, len(parts[q]), seed, first_index=first + int(parts[q][0]), steps=sim_steps,
+                                          obs_motion=_abi.OBSMOVE_PREDICTED, hold_on_failure=hold)
 
     def loops(hold):
         th = [threading.Thread(target=run, args=(q, hold)) for q in range(F)]
@@ -168,7 +173,7 @@ def closed_loop_bench(args, bs, cfg, x0, xs, obs, workload, grp, local_rank):
             t_.start()
         for t_ in th:
             t_.join()
-        return {k: np.concatenate([r_[k] for r_ in res]) for k in ("status", "iters", "x_hist", "u_hist")}
+        return {k: np.concatenate([r_[k] for r_ in res]) for k in ("status", "iters", "x_hist", "u_hist", "x0", "obs0")}
 
     grp.barrier()
     t0 = time.perf_counter()
@@ -182,6 +187,8 @@ def closed_loop_bench(args, bs, cfg, x0, xs, obs, workload, grp, local_rank):
     tms = [h_.timing() for h_ in H]
     held = loops(True)                                        # the same scenes once more with the hold-and-shift fallback (untimed)
     status, iters = out["status"], out["iters"]
+    x0, obs = out["x0"], out["obs0"]                          # the scenes the device drew
+    xs = np.tile(x0[:1] * 0 + np.array([400.0, 3.5, 0.0, 30.0]), (len(x0), 1))
     B = len(x0)
     solved = int((status == 0).sum())
 
@@ -214,7 +221,7 @@ def closed_loop_bench(args, bs, cfg, x0, xs, obs, workload, grp, local_rank):
                    "scenes_all_steps_solved": int(sums[2]), "min_h_scenes_all_solved": m_ok, "min_h_all_scenes": m_all, "scenes_with_collision": n_coll,
                    "with_hold_on_failure": {"scenes_all_steps_solved": nh_ok, "min_h_scenes_all_solved": mh_ok, "min_h_all_scenes": mh_all,
                                             "scenes_with_collision": nh_coll, "failed_steps": int((held["status"] != 0).sum())},
-                   "iters_mean": float(iters.mean()), "iters_max": int(iters.max()), "host_pointer_entry": True, "loops_in_flight": F,
+                   "iters_mean": float(iters.mean()), "iters_max": int(iters.max()), "scenes_drawn_on_device": True, "loops_in_flight": F,
                    "launches": launches, "restoration": bool(cfg.restoration), "collective": "none (scenes are independent for their whole horizon)",
                    "parity": PARITY_NOTE},
         "roofline": {"bound": "hbm", "achieved": abytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -203,6 +203,37 @@ int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps,
                      const double* x0, const double* xs, double* obs_state, int32_t obs_motion, int32_t flags,
                      double* x_hist, double* u_hist, int32_t* status_hist, int32_t* iters_hist);
 
+/* ---- scene generation on the device -----------------------------------------------------------------------
+ * Counter-based random scenes (Philox4x32-10 keyed by `seed`, counter = global scene index): scene i is the same whichever GPU,
+ * batch or chunk it is generated in, so 8 GPUs draw disjoint slices of one Monte-Carlo population from (seed, first_index).
+ * Distributions of SURVEY.md 8(d) (the samplers of mpc_motion_planning_amd/scenes.py, rejection included):
+ *   MPCB_SCENES_C2  x0 = [U(0,30), U(-0.5,4.5), U(-0.1,0.1), U(5,25)], rejected inside the shipped obstacle's ellipse (h < 0.05);
+ *                   xs = [400,3.5,0,30], obs = [50,3.5,0,8,4.8,1.8]                       (main_cbf_kin_c_sim.py:45-55)
+ *   MPCB_SCENES_C3  the same x0; n_obs moving obstacles x U(30,120), y in {0,3.5} +- 0.3, theta 0, v U(5,15), 4.8 x 1.8 m,
+ *                   rejected when they overlap each other or the ego (also the scenes of C5)
+ *   MPCB_SCENES_C4  dynamic bicycle: x0 = [U(0,30), U(-0.5,4.5), U(-0.05,0.05), U(8,20), 0, 0], xs = [600,3.5,0,15,0,0],
+ *                   n_obs static obstacles x U(40,200), y in {-3.5,0,3.5,7} +- 0.3 (main_cbf_dyn_c_sim.py:44-51)
+ * Device pointers x0 [B,nx], xs [B,nx], obs [B,n_obs,6]; asynchronous on the handle's stream. */
+#define MPCB_SCENES_C2 2
+#define MPCB_SCENES_C3 3
+#define MPCB_SCENES_C4 4
+int mpcb_sample_scenes(mpcb_handle* h, int32_t kind, int32_t B, uint64_t seed, uint64_t first_index,
+                       double* d_x0, double* d_xs, double* d_obs);
+/* mpcb_closed_loop on scenes drawn on the device (nothing but the histories crosses PCIe).  x0_out [B,nx] and obs0_out
+ * [B,n_obs,6] (may be NULL) return the scenes that were drawn. */
+int mpcb_closed_loop_sampled(mpcb_handle* h, int32_t kind, int32_t B, uint64_t seed, uint64_t first_index, int32_t steps,
+                             int32_t obs_motion, int32_t flags, double* x0_out, double* obs0_out,
+                             double* x_hist, double* u_hist, int32_t* status_hist, int32_t* iters_hist);
+/* Device twins of the reference's scene helpers (host pointers in and out; the work is done by the device kernels the closed
+ * loop uses):
+ *   mpcb_predict_obstacles  constant-velocity roll-out [n,6] -> [n,N+1,6]            Obs_prediction.py:3-40
+ *   mpcb_ref_path_window    straight 1 m-spaced global path from x_start to xs[0] at (xs[1], xs[2], xs[3]); per instance the
+ *                           nearest path point searched from last_idx - 5 (first local minimum of the distance) and the
+ *                           (N_p+1)-point preview window resampled from there; last_idx is updated   RefPathGenerator.py:9-59 */
+int mpcb_predict_obstacles(mpcb_handle* h, int32_t n, int32_t N, double dt, const double* obs, double* traj);
+int mpcb_ref_path_window(mpcb_handle* h, int32_t B, double x_start, const double* x0, const double* xs, double T_horizon, double dt,
+                         int32_t* last_idx, double* window);
+
 /* ---- multi-GPU ---------------------------------------------------------------------------------------------
  * Instances are independent NLPs (every `solver(...)` call of main_cbf_kin_c_sim.py:100 stands alone), so a batch is cut into
  * contiguous shards, one per GPU, with NO data-path collective; one RCCL all-gather of the converged trajectories over xGMI

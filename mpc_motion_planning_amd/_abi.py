@@ -20,6 +20,7 @@ CL_HOLD_ON_FAILURE, CL_ADVANCE_FIRST_ONLY = 1, 2
 OBSMOVE_STATIC, OBSMOVE_PREDICTED, OBSMOVE_CURRENT = 0, 1, 2
 NX_MAX, NU, NOBS_MAX, N_MAX = 6, 2, 8, 63
 UNIQUE_ID_BYTES = 128
+SCENES_C2, SCENES_C3, SCENES_C4 = 2, 3, 4
 
 _d = C.c_double
 _i = C.c_int32

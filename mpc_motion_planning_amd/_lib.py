@@ -30,6 +30,10 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "mpcb_solve_trace": (C.c_int, [_H, _PD, _PD, _PD, C.c_int32, _PD, _PD, _PI, _PI, _PD]),
     "mpcb_closed_loop": (C.c_int, [_H, C.c_int32, C.c_int32, _PD, _PD, _PD, C.c_int32, C.c_int32, _PD, _PD, _PI, _PI]),
+    "mpcb_sample_scenes": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mpcb_closed_loop_sampled": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, _PD, _PD, _PD, _PD, _PI, _PI]),
+    "mpcb_predict_obstacles": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_double, _PD, _PD]),
+    "mpcb_ref_path_window": (C.c_int, [_H, C.c_int32, C.c_double, _PD, _PD, C.c_double, C.c_double, _PI, _PD]),
     "mpcb_shard_bounds": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mpcb_comm_unique_id": (C.c_int, [C.c_void_p]),
     "mpcb_comm_init_rank": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32]),

@@ -142,6 +142,98 @@ __global__ void mpcb_predict_obs(int total, int N, double T, const double* __res
   }
 }
 
+// ---- scene generation: Philox4x32-10 (Salmon et al., SC'11), key = seed, counter = (scene index, draw block) --------------
+struct SceneRng {
+  uint32_t k0, k1, i0, i1, block, buf[4]; int have;
+  __device__ SceneRng(uint64_t seed, uint64_t index) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)), i0((uint32_t)index), i1((uint32_t)(index >> 32)), block(0), have(0) {}
+  __device__ void refill() {
+    uint32_t c0 = i0, c1 = i1, c2 = block++, c3 = 0x4d504342u /* "MPCB" */, a = k0, b = k1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0, h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+      const uint32_t n0 = h1 ^ c1 ^ a, n2 = h0 ^ c3 ^ b;
+      c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+      a += 0x9E3779B9u; b += 0xBB67AE85u;
+    }
+    buf[0] = c0; buf[1] = c1; buf[2] = c2; buf[3] = c3; have = 4;
+  }
+  __device__ uint32_t next() { if (!have) refill(); return buf[--have]; }
+  __device__ double uniform(double lo, double hi) {            // 53 random bits -> [0, 1)
+    const uint64_t hi32 = next(), lo32 = next();
+    const double u = (double)(((hi32 << 32) | lo32) >> 11) * (1.0 / 9007199254740992.0);
+    return lo + (hi - lo) * u;
+  }
+  __device__ int choice(int n) { return (int)(next() % (uint32_t)n); }
+};
+
+// one thread per scene; rejection sampling as mpc_motion_planning_amd/scenes.py (sample_c2 / sample_c3 / sample_c4), at most 256 draws
+__global__ __launch_bounds__(128) void mpcb_sample_kernel(const mpcb_config c, int kind, int B, uint64_t seed, uint64_t first,
+                                                         double* __restrict__ x0, double* __restrict__ xs, double* __restrict__ obs) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  SceneRng g(seed, first + (uint64_t)b);
+  const int no = c.n_obs, nx = c.model == MPCB_MODEL_DYN ? 6 : 4;
+  double e[6] = {0, 0, 0, 0, 0, 0}, o[MPCB_NOBS_MAX][6];
+  for (int attempt = 0; attempt < 256; ++attempt) {
+    bool ok = true;
+    if (kind == MPCB_SCENES_C4) {
+      e[0] = g.uniform(0, 30); e[1] = g.uniform(-0.5, 4.5); e[2] = g.uniform(-0.05, 0.05); e[3] = g.uniform(8, 20); e[4] = 0; e[5] = 0;
+      const double lanes[4] = {-3.5, 0.0, 3.5, 7.0};
+      for (int j = 0; j < no; ++j) {
+        o[j][0] = g.uniform(40, 200); o[j][1] = lanes[g.choice(4)] + g.uniform(-0.3, 0.3); o[j][2] = 0; o[j][3] = 0; o[j][4] = 0; o[j][5] = 0;
+        const double dx = (e[0] - o[j][0]) / 4.0, dy = (e[1] - o[j][1]) / 1.0;              // dyn.py:240-243, fixed 4 x 1 semi-axes
+        ok = ok && (dx * dx + dy * dy - 1.0 >= 1.5);
+      }
+    } else {
+      e[0] = g.uniform(0, 30); e[1] = g.uniform(-0.5, 4.5); e[2] = g.uniform(-0.1, 0.1); e[3] = g.uniform(5, 25);
+      for (int j = 0; j < no; ++j) {
+        if (kind == MPCB_SCENES_C2) { o[j][0] = 50.0; o[j][1] = 3.5; o[j][2] = 0.0; o[j][3] = 8.0; }            // main_cbf_kin_c_sim.py:55
+        else { o[j][0] = g.uniform(30, 120); o[j][1] = (g.choice(2) ? 3.5 : 0.0) + g.uniform(-0.3, 0.3); o[j][2] = 0.0; o[j][3] = g.uniform(5, 15); }
+        o[j][4] = 4.8; o[j][5] = 1.8;
+        const double sx = c.ego_hl + o[j][4] / 2 + c.safe_disl, sy = c.ego_hw + o[j][5] / 2 + c.safe_disw;     // kin.py:242-243
+        const double dx = (e[0] - o[j][0]) / sx, dy = (e[1] - o[j][1]) / sy;
+        ok = ok && (dx * dx + dy * dy - 1.0 >= 0.05);
+        for (int i = 0; i < j; ++i) ok = ok && (fabs(o[i][0] - o[j][0]) > 12.0 || fabs(o[i][1] - o[j][1]) > 2.5);   // obstacles apart
+      }
+    }
+    if (ok) break;
+  }
+  const double xs_kin[4] = {400.0, 3.5, 0.0, 30.0}, xs_dyn[6] = {600.0, 3.5, 0.0, 15.0, 0.0, 0.0};           // main_cbf_kin_c_sim.py:49, main_cbf_dyn_c_sim.py:48
+  for (int q = 0; q < nx; ++q) { x0[(size_t)b * nx + q] = e[q]; xs[(size_t)b * nx + q] = nx == 6 ? xs_dyn[q] : xs_kin[q]; }
+  for (int j = 0; j < no; ++j) for (int q = 0; q < 6; ++q) obs[((size_t)b * no + j) * 6 + q] = o[j][q];
+}
+
+// straight global path + preview window per instance (RefPathGenerator.py:9-59).  Path point i = (x_start + i * step, xs[1], xs[2], xs[3]),
+// step = +-1 m towards xs[0]; M = number of points of np.arange(x_start, xs[0] + step, step).
+__global__ __launch_bounds__(128) void mpcb_ref_window_kernel(int B, double x_start, const double* __restrict__ x0, const double* __restrict__ xs,
+                                                             double T_horizon, double dt, int N_p, int32_t* __restrict__ last_idx, double* __restrict__ win) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* e = x0 + (size_t)b * 4; const double* t = xs + (size_t)b * 4;
+  const double step = t[0] > x_start ? 1.0 : -1.0;
+  const int M = (int)ceil(((t[0] + step) - x_start) / step);                          // len(np.arange(start, stop, step))
+  const double pv = 0.5 * e[3] + 0.5 * t[3];                                          // preview speed        :29
+  const int pidx = (int)(pv * T_horizon / 1.0);                                       // int(preview_v * T_horizon / step_x), step_x = 1
+  const int last = last_idx[b];
+  const int lo = last - 5 > 0 ? last - 5 : 0, hi = last + pidx < M ? last + pidx : M;
+  int mi = lo; double best = INFINITY;
+  for (int i = lo; i < hi; ++i) {                                                     // first local minimum of the distance    :36-45
+    const double dx = (x_start + i * step) - e[0], dy = t[1] - e[1];
+    const double d = sqrt(dx * dx + dy * dy);
+    if (d < best) { best = d; mi = i; } else break;
+  }
+  last_idx[b] = mi;
+  const double lstep = ((double)(mi + pidx) - (double)mi) / (double)N_p;              // np.linspace(mi, mi + pidx, N_p + 1)
+  for (int j = 0; j <= N_p; ++j) {
+    double v = j == N_p ? (double)(mi + pidx) : (double)j * lstep + (double)mi;
+    v = v < 0 ? 0 : v > (double)(M - 1) ? (double)(M - 1) : v;                        // np.clip(., 0, ref_len - 1).astype(int)
+    const int idx = (int)v;
+    double* w = win + ((size_t)b * (N_p + 1) + j) * 4;
+    w[0] = x_start + idx * step; w[1] = t[1]; w[2] = t[2]; w[3] = t[3];
+  }
+}
+
 }  // namespace
 
 struct mpcb_handle {
@@ -758,11 +850,13 @@ int mpcb_solve_trace(mpcb_handle* h, const double* x0, const double* xs, const d
   return MPCB_OK;
 }
 
-int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps, const double* x0, const double* xs, double* obs_state, int32_t obs_motion,
-                     int32_t flags, double* x_hist, double* u_hist, int32_t* status_hist, int32_t* iters_hist) {
+// the closed loop; scenes either come from the host (x0, xs, obs_state) or are drawn on the device (sample_kind != 0)
+static int closed_loop_impl(mpcb_handle* h, int32_t B, int32_t steps, const double* x0, const double* xs, double* obs_state, int32_t obs_motion,
+                            int32_t flags, double* x_hist, double* u_hist, int32_t* status_hist, int32_t* iters_hist,
+                            int32_t sample_kind, uint64_t seed, uint64_t first_index, double* x0_out, double* obs0_out) {
   if (!h) return MPCB_E_INVALID;
-  if (B < 0 || steps < 0 || !x0 || !xs) return fail(h, MPCB_E_INVALID, "B < 0, steps < 0 or a required pointer is NULL");
-  if (h->cfg.n_obs > 0 && !obs_state) return fail(h, MPCB_E_INVALID, "n_obs = %d but obs_state is NULL", h->cfg.n_obs);
+  if (B < 0 || steps < 0 || (!sample_kind && (!x0 || !xs))) return fail(h, MPCB_E_INVALID, "B < 0, steps < 0 or a required pointer is NULL");
+  if (!sample_kind && h->cfg.n_obs > 0 && !obs_state) return fail(h, MPCB_E_INVALID, "n_obs = %d but obs_state is NULL", h->cfg.n_obs);
   if (obs_motion < MPCB_OBSMOVE_STATIC || obs_motion > MPCB_OBSMOVE_CURRENT) return fail(h, MPCB_E_INVALID, "unknown obs_motion %d", obs_motion);
   if (flags & ~(MPCB_CL_HOLD_ON_FAILURE | MPCB_CL_ADVANCE_FIRST_ONLY)) return fail(h, MPCB_E_INVALID, "unknown flags 0x%x", flags);
   const int predict = obs_motion == MPCB_OBSMOVE_PREDICTED;
@@ -786,9 +880,16 @@ int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps, const double* x0,
   { Carve dry{nullptr}; carve(dry); int rc = ensure_scratch(h, dry.bytes()); if (rc != MPCB_OK) return rc; }
   { Carve cv{(char*)h->d_buf}; carve(cv); }
   hipStream_t s = h->stream;
-  HIP_TRY(h, hipMemcpyAsync(d_x0, x0, (size_t)B * nx * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(h, hipMemcpyAsync(d_xs, xs, (size_t)B * nx * 8, hipMemcpyHostToDevice, s));
-  if (d_obs) HIP_TRY(h, hipMemcpyAsync(d_obs, obs_state, (size_t)B * no * 6 * 8, hipMemcpyHostToDevice, s));
+  if (sample_kind) {
+    int rc = mpcb_sample_scenes(h, sample_kind, B, seed, first_index, d_x0, d_xs, d_obs);
+    if (rc != MPCB_OK) return rc;
+    if (x0_out) HIP_TRY(h, hipMemcpyAsync(x0_out, d_x0, (size_t)B * nx * 8, hipMemcpyDeviceToHost, s));
+    if (obs0_out && d_obs) HIP_TRY(h, hipMemcpyAsync(obs0_out, d_obs, (size_t)B * no * 6 * 8, hipMemcpyDeviceToHost, s));
+  } else {
+    HIP_TRY(h, hipMemcpyAsync(d_x0, x0, (size_t)B * nx * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(d_xs, xs, (size_t)B * nx * 8, hipMemcpyHostToDevice, s));
+    if (d_obs) HIP_TRY(h, hipMemcpyAsync(d_obs, obs_state, (size_t)B * no * 6 * 8, hipMemcpyHostToDevice, s));
+  }
   HIP_TRY(h, hipMemsetAsync(d_z0, 0, (size_t)B * nz * 8, s));                  // u0 = 0, next_states = 0 (main_cbf_kin_c_sim.py:47-50)
   HIP_TRY(h, hipMemcpy2DAsync(d_xh, (size_t)(steps + 1) * nx * 8, d_x0, (size_t)nx * 8, (size_t)nx * 8, B, hipMemcpyDeviceToDevice, s));
   const int move = obs_motion == MPCB_OBSMOVE_STATIC ? 0 : (flags & MPCB_CL_ADVANCE_FIRST_ONLY) ? 2 : 1;
@@ -816,7 +917,70 @@ int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps, const double* x0,
   if (u_hist) HIP_TRY(h, hipMemcpyAsync(u_hist, d_uh, (size_t)B * steps * 2 * 8, hipMemcpyDeviceToHost, s));
   if (status_hist) HIP_TRY(h, hipMemcpyAsync(status_hist, d_st, (size_t)B * steps * 4, hipMemcpyDeviceToHost, s));
   if (iters_hist) HIP_TRY(h, hipMemcpyAsync(iters_hist, d_it, (size_t)B * steps * 4, hipMemcpyDeviceToHost, s));
-  if (d_obs) HIP_TRY(h, hipMemcpyAsync(obs_state, d_obs, (size_t)B * no * 6 * 8, hipMemcpyDeviceToHost, s));
+  if (d_obs && obs_state) HIP_TRY(h, hipMemcpyAsync(obs_state, d_obs, (size_t)B * no * 6 * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  return MPCB_OK;
+}
+
+int mpcb_closed_loop(mpcb_handle* h, int32_t B, int32_t steps, const double* x0, const double* xs, double* obs_state, int32_t obs_motion,
+                     int32_t flags, double* x_hist, double* u_hist, int32_t* status_hist, int32_t* iters_hist) {
+  return closed_loop_impl(h, B, steps, x0, xs, obs_state, obs_motion, flags, x_hist, u_hist, status_hist, iters_hist, 0, 0, 0, nullptr, nullptr);
+}
+
+int mpcb_closed_loop_sampled(mpcb_handle* h, int32_t kind, int32_t B, uint64_t seed, uint64_t first_index, int32_t steps, int32_t obs_motion,
+                             int32_t flags, double* x0_out, double* obs0_out, double* x_hist, double* u_hist, int32_t* status_hist, int32_t* iters_hist) {
+  if (!h) return MPCB_E_INVALID;
+  if (kind != MPCB_SCENES_C2 && kind != MPCB_SCENES_C3 && kind != MPCB_SCENES_C4) return fail(h, MPCB_E_INVALID, "unknown scene kind %d", kind);
+  return closed_loop_impl(h, B, steps, nullptr, nullptr, nullptr, obs_motion, flags, x_hist, u_hist, status_hist, iters_hist, kind, seed, first_index, x0_out, obs0_out);
+}
+
+int mpcb_sample_scenes(mpcb_handle* h, int32_t kind, int32_t B, uint64_t seed, uint64_t first_index, double* d_x0, double* d_xs, double* d_obs) {
+  if (!h) return MPCB_E_INVALID;
+  if (B < 0 || !d_x0 || !d_xs || (h->cfg.n_obs > 0 && !d_obs)) return fail(h, MPCB_E_INVALID, "B < 0 or a required pointer is NULL");
+  if (kind != MPCB_SCENES_C2 && kind != MPCB_SCENES_C3 && kind != MPCB_SCENES_C4) return fail(h, MPCB_E_INVALID, "unknown scene kind %d", kind);
+  if ((kind == MPCB_SCENES_C4) != (h->cfg.model == MPCB_MODEL_DYN)) return fail(h, MPCB_E_INVALID, "scene kind %d does not fit the handle's model", kind);
+  if (kind == MPCB_SCENES_C2 && h->cfg.n_obs > 1) return fail(h, MPCB_E_INVALID, "MPCB_SCENES_C2 has one obstacle, the handle has n_obs = %d", h->cfg.n_obs);
+  if (B == 0) return MPCB_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(mpcb_sample_kernel, dim3((B + 127) / 128), dim3(128), 0, h->stream, h->cfg, kind, B, seed, first_index, d_x0, d_xs, d_obs);
+  HIP_TRY(h, hipGetLastError());
+  return MPCB_OK;
+}
+
+int mpcb_predict_obstacles(mpcb_handle* h, int32_t n, int32_t N, double dt, const double* obs, double* traj) {
+  if (!h || n < 0 || N < 1 || !(dt > 0) || !obs || !traj) return fail(h, MPCB_E_INVALID, "bad argument");
+  if (n == 0) return MPCB_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  double *d_o, *d_t;
+  auto carve = [&](Carve& cv) { d_o = cv.take<double>((size_t)n * 6); d_t = cv.take<double>((size_t)n * (N + 1) * 6); };
+  { Carve dry{nullptr}; carve(dry); int rc = ensure_scratch(h, dry.bytes()); if (rc != MPCB_OK) return rc; }
+  { Carve cv{(char*)h->d_buf}; carve(cv); }
+  HIP_TRY(h, hipMemcpyAsync(d_o, obs, (size_t)n * 6 * 8, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(mpcb_predict_obs, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, N, dt, (const double*)nullptr, d_o, d_t);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(traj, d_t, (size_t)n * (N + 1) * 6 * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPCB_OK;
+}
+
+int mpcb_ref_path_window(mpcb_handle* h, int32_t B, double x_start, const double* x0, const double* xs, double T_horizon, double dt,
+                         int32_t* last_idx, double* window) {
+  if (!h || B < 0 || !x0 || !xs || !last_idx || !window || !(dt > 0) || !(T_horizon > 0)) return fail(h, MPCB_E_INVALID, "bad argument");
+  if (B == 0) return MPCB_OK;
+  const int N_p = (int)(T_horizon / dt);                                              // RefPathGenerator.py:32
+  HIP_TRY(h, hipSetDevice(h->device));
+  double *d_x0, *d_xs, *d_w; int32_t* d_li;
+  auto carve = [&](Carve& cv) { d_x0 = cv.take<double>((size_t)B * 4); d_xs = cv.take<double>((size_t)B * 4); d_w = cv.take<double>((size_t)B * (N_p + 1) * 4); d_li = cv.take<int32_t>(B); };
+  { Carve dry{nullptr}; carve(dry); int rc = ensure_scratch(h, dry.bytes()); if (rc != MPCB_OK) return rc; }
+  { Carve cv{(char*)h->d_buf}; carve(cv); }
+  hipStream_t s = h->stream;
+  HIP_TRY(h, hipMemcpyAsync(d_x0, x0, (size_t)B * 4 * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(d_xs, xs, (size_t)B * 4 * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(h, hipMemcpyAsync(d_li, last_idx, (size_t)B * 4, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(mpcb_ref_window_kernel, dim3((B + 127) / 128), dim3(128), 0, s, B, x_start, d_x0, d_xs, T_horizon, dt, N_p, d_li, d_w);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(window, d_w, (size_t)B * (N_p + 1) * 4 * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(last_idx, d_li, (size_t)B * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(h, hipStreamSynchronize(s));
   return MPCB_OK;
 }

@@ -185,6 +185,47 @@ class BatchSolver:
                                      iptr(st), iptr(it)), self._h)
         return dict(x_hist=xh, u_hist=uh, status=st, iters=it, obs_state=ob)
 
+    # ----- scene generation on the device (include/mpcbatch.h, "scene generation") ----------------------------------
+    def sample_scenes(self, kind, B, seed, first_index=0):
+        """B scenes of distribution `kind` (_abi.SCENES_C2 / C3 / C4) drawn on the device with the counter-based generator;
+        scene i of a population is the same whichever call or GPU draws it (global index first_index + i).  Downloads
+        (x0 [B,nx], xs [B,nx], obs [B,n_obs,6])."""
+        no = self.cfg.n_obs
+        d_x0 = self.device_array((B, self.nx)); d_xs = self.device_array((B, self.nx)); d_ob = self.device_array((B, max(no, 1), 6))
+        check(lib().mpcb_sample_scenes(self._h, int(kind), int(B), int(seed), int(first_index), d_x0.ptr, d_xs.ptr, d_ob.ptr), self._h)
+        self.sync()
+        out = d_x0.download(), d_xs.download(), d_ob.download()[:, :no]
+        for d in (d_x0, d_xs, d_ob):
+            d.free()
+        return out
+
+    def closed_loop_sampled(self, kind, B, seed, first_index=0, steps=80, obs_motion=_abi.OBSMOVE_STATIC, hold_on_failure=False,
+                            advance_first_only=False):
+        """closed_loop on scenes drawn on the device; also returns the scenes (x0, obs0)."""
+        no = self.cfg.n_obs
+        x0 = np.empty((B, self.nx)); ob = np.empty((B, no, 6)) if no else None
+        xh = np.empty((B, steps + 1, self.nx)); uh = np.empty((B, steps, 2))
+        st = np.empty((B, steps), np.int32); it = np.empty((B, steps), np.int32)
+        flags = (_abi.CL_HOLD_ON_FAILURE if hold_on_failure else 0) | (_abi.CL_ADVANCE_FIRST_ONLY if advance_first_only else 0)
+        check(lib().mpcb_closed_loop_sampled(self._h, int(kind), int(B), int(seed), int(first_index), int(steps), int(obs_motion), flags,
+                                             dptr(x0), dptr(ob), dptr(xh), dptr(uh), iptr(st), iptr(it)), self._h)
+        return dict(x0=x0, obs0=ob, x_hist=xh, u_hist=uh, status=st, iters=it)
+
+    def predict_obstacles(self, obs, dt, N):
+        """Device twin of Obs_prediction.obs_prediction: obs [n,6] -> [n,N+1,6]."""
+        obs = np.ascontiguousarray(np.asarray(obs, dtype=np.float64).reshape(-1, 6))
+        out = np.empty((len(obs), N + 1, 6))
+        check(lib().mpcb_predict_obstacles(self._h, len(obs), int(N), float(dt), dptr(obs), dptr(out)), self._h)
+        return out
+
+    def ref_path_window(self, x_start, x0, xs, T_horizon, dt, last_idx):
+        """Device twin of RefPathGenerator.define_ref_path + find_ref_traj for B instances: (window [B,N_p+1,4], min_idx [B])."""
+        x0 = np.ascontiguousarray(np.asarray(x0, dtype=np.float64).reshape(-1, 4)); xs = np.ascontiguousarray(np.asarray(xs, dtype=np.float64).reshape(-1, 4))
+        li = np.ascontiguousarray(np.asarray(last_idx, dtype=np.int32).reshape(-1))
+        win = np.empty((len(x0), int(T_horizon / dt) + 1, 4))
+        check(lib().mpcb_ref_path_window(self._h, len(x0), float(x_start), dptr(x0), dptr(xs), float(T_horizon), float(dt), iptr(li), dptr(win)), self._h)
+        return win, li
+
     # ----- device-resident path (bench.py, multi-GPU plumbing) -------------------------------------------
     def device_array(self, shape, dtype=np.float64):
         return DeviceArray(self, shape, dtype)
