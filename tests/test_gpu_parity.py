@@ -705,3 +705,34 @@ def test_scene_generation_on_device(gpu_solver_factory):
     h = bs.closed_loop(r["x0"], np.tile(scenes.SHIPPED_XS, (64, 1)), r["obs0"], steps=5, obs_motion=_abi.OBSMOVE_PREDICTED)
     for k in ("x_hist", "u_hist", "status", "iters"):
         assert np.array_equal(r[k], h[k], equal_nan=True) if r[k].dtype.kind == "f" else np.array_equal(r[k], h[k]), k
+
+
+@pytest.mark.parametrize("conf", ["C2", "C3", "C4"])
+def test_independent_kkt_certificate_on_256_solved_instances(gpu_solver_factory, conf):
+    """The only evidence that shares neither code nor algorithm with the kernel: oracle/kkt_check.py writes the reference's NLP a
+    second time in its flat z / g ordering (complex-step derivatives, no hand-written algebra) and judges (z, lam_g, lam_x) of
+    the DEVICE by the first-order conditions in IPOPT's sign convention.  256 solved instances of each benchmark configuration
+    (C2: one static obstacle, C3: three predicted obstacles, C4: dynamic bicycle with three obstacles, reference row sqrt(h) >= 1)."""
+    from oracle import kkt_check
+    if conf == "C2":
+        cfg = default_config(N=30, n_obs=1); x0, xs, obs = scenes.sample_c2(400, seed=50)
+        nlp = lambda b: kkt_check.KinNlp(30, 0.1, x0[b], xs[b], obs[b])                       # noqa: E731
+    elif conf == "C3":
+        cfg = default_config(N=30, n_obs=3); x0, xs, _, obs = scenes.sample_c3(400, N=30, dt=0.1, seed=51)
+        nlp = lambda b: kkt_check.KinNlp(30, 0.1, x0[b], xs[b], obs[b])                       # noqa: E731
+    else:
+        cfg = default_config(model=_abi.MODEL_DYN, N=40, n_obs=3); x0, xs, obs = scenes.sample_c4(300, seed=52, n_obs=3)
+        nlp = lambda b: kkt_check.DynNlp(40, 0.1, x0[b], xs[b], obs[b])                       # noqa: E731
+    r = gpu_solver_factory(cfg).solve_batch(x0, xs, obs, multipliers=True)
+    idx = np.nonzero(r["status"] == 0)[0][:256]
+    assert len(idx) == 256
+    worst = dict(stationarity=0.0, feas_g=0.0, feas_x=0.0, compl=0.0)
+    for b in idx:
+        n_ = nlp(b)
+        lg = n_.convert_obstacle_multipliers(r["z"][b], r["lam_g"][b]) if conf == "C4" else r["lam_g"][b]
+        c = kkt_check.certificate(n_, r["z"][b], lg, r["lam_x"][b])
+        assert c["stationarity"] <= 1e-6 * c["lam_scale"] and c["feas_g"] <= 2e-8 and c["feas_x"] <= 1e-7 and c["compl"] <= 1e-3 and c["sign"] == 0.0, (b, c)
+        assert c["f"] == pytest.approx(r["obj"][b], rel=1e-11)
+        for k in worst:
+            worst[k] = max(worst[k], float(c[k] / (c["lam_scale"] if k == "stationarity" else 1.0)))
+    print(conf, "worst over 256:", worst)
