@@ -68,6 +68,9 @@ constexpr int FILTER_MAX = 64;
 // reduced theta by less than the factor TRIG_THETA
 constexpr double RS_RHO = 1000.0, RS_KAPPA = 0.5, RS_GAP = 10.0, TRIG_ALPHA = 0.05, TRIG_THETA = 0.8;
 constexpr int TRIG_K = 5;
+// effort bounds of the restoration phase per instance: entries into it, iterations inside it (all entries together); beyond them the
+// solve ends with MPCB_ST_RESTO_FAILED (a launch ends with its slowest instance: the phase must not run to max_iter)
+constexpr int RS_MAX_CALLS = 3, RS_MAX_ITERS = 40;
 // hand-over record of an instance that needs the restoration pass
 constexpr int WK_MU = 0, WK_THMAX = 1, WK_THMIN = 2, WK_ITERS = 3, WK_DW = 4, WK_SIZE = 8;
 // per-node cost table of the RESTO instantiations, [row][64] in LDS (lane = node): scaled weights osc*2*Qc, reference point,
@@ -643,7 +646,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   // restoration-phase state (RESTO instantiation): the main phase's mu and filter bounds while the restoration runs, the entry
   // pair of the main filter, the violation at entry, iterations inside the phase; `enter` asks the loop top to start the phase
   double mu_main = 0, tmax_main = 0, tmin_main = 0, fm_theta = 0, fm_phi = 0, th_entry = 0;
-  int rit = 0, slow_run = 0;
+  int rit = 0, slow_run = 0, n_rcalls = 0, n_riters = 0;
   double slow_theta0 = 0;
   bool enter = false;
   double n_el = 0;                       // number of elastic rows (constant of the instance)
@@ -679,7 +682,9 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
 #pragma clang loop unroll(disable)
     for (;;) {
       if (++trips > 3 * c.max_iter + 50) { status = MPCB_ST_RESTO_FAILED; break; }   // (phase changes do not count as iterations)
+      if (RESTO && enter && n_rcalls >= RS_MAX_CALLS) { status = MPCB_ST_RESTO_FAILED; break; }
       if (RESTO && enter) {
+        ++n_rcalls;
         // ----- entry into the restoration phase (oracle: Solver::restoration) ------------------------------------------------
         enter = false;
         mu_main = mu; tmax_main = theta_max; tmin_main = theta_min;
@@ -866,6 +871,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
             const double gap = (RS_GAP * n_vr * mu + 0.5 * (double)((NX + NU) * N) * sqrt(mu)) / RS_RHO;
             if (em <= K_EPS * mu && V > gap + 1e-6 && theta <= 0.01 * V) { status = MPCB_ST_INFEASIBLE; break; }
             if (iters >= c.max_iter) { status = MPCB_ST_MAXITER; break; }
+            if (n_riters >= RS_MAX_ITERS) { status = MPCB_ST_RESTO_FAILED; break; }
           } else {
             // ----- back to the main phase: original cost, mu and filter bounds; lam = 0; bound duals kept unless one exceeds 1000
             rs = false; osc = os; write_main_cost();
@@ -1365,7 +1371,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       theta = tht; fval = ft; logsum = lst;
       if (!isfinite(theta) || !isfinite(fval)) { status = MPCB_ST_NUMERIC; break; }
       ++iters;
-      if (RESTO && rs) ++rit;
+      if (RESTO && rs) { ++rit; ++n_riters; }
       else if (c.restoration) {
         // early entry into restoration: TRIG_K accepted steps in a row shorter than TRIG_ALPHA that together reduced theta by less
         // than the factor TRIG_THETA (a slack pinned at its bound with the row still violated: the pattern of an infeasible

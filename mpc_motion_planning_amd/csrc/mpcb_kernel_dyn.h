@@ -506,7 +506,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
 
   // restoration-phase state (see mpcb_solve_kin)
   double mu_main = 0, tmax_main = 0, tmin_main = 0, fm_theta = 0, fm_phi = 0, th_entry = 0;
-  int rit = 0, slow_run = 0;
+  int rit = 0, slow_run = 0, n_rcalls = 0, n_riters = 0;
   double slow_theta0 = 0;
   bool enter = false;
   double n_el = 0;
@@ -541,7 +541,9 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
 #pragma clang loop unroll(disable)
     for (;;) {
       if (++trips > 3 * c.max_iter + 50) { status = MPCB_ST_RESTO_FAILED; break; }
+      if (RESTO && enter && n_rcalls >= RS_MAX_CALLS) { status = MPCB_ST_RESTO_FAILED; break; }
       if (RESTO && enter) {
+        ++n_rcalls;
         // ----- entry into the restoration phase (oracle: Solver::restoration; comments in mpcb_solve_kin) ----------------------
         enter = false;
         mu_main = mu; tmax_main = theta_max; tmin_main = theta_min;
@@ -732,6 +734,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
             const double gap = (RS_GAP * n_vr * mu + 0.5 * (double)((NX + NU) * N) * sqrt(mu)) / RS_RHO;
             if (em <= K_EPS * mu && V > gap + 1e-6 && theta <= 0.01 * V) { status = MPCB_ST_INFEASIBLE; break; }
             if (iters >= c.max_iter) { status = MPCB_ST_MAXITER; break; }
+            if (n_riters >= RS_MAX_ITERS) { status = MPCB_ST_RESTO_FAILED; break; }
           } else {
             // ----- back to the main phase
             rs = false; osc = os; write_main_cost();
@@ -1191,7 +1194,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       theta = tht; fval = ft; logsum = lst;
       if (!isfinite(theta) || !isfinite(fval)) { status = MPCB_ST_NUMERIC; break; }
       ++iters;
-      if (RESTO && rs) ++rit;
+      if (RESTO && rs) { ++rit; ++n_riters; }
       else if (c.restoration) {       // early entry into restoration (see mpcb_solve_kin)
         if (alpha < TRIG_ALPHA && theta > 1e-6) { if (slow_run == 0) slow_theta0 = th0; ++slow_run; } else slow_run = 0;
         if (slow_run >= TRIG_K && theta > TRIG_THETA * slow_theta0) {

@@ -258,6 +258,7 @@ struct Opt {   // line-search / barrier constants of IPOPT (Waechter-Biegler 200
   double resto_rho = 1000.0;       // IPOPT resto_penalty_parameter
   double resto_kappa = 0.5;        // leave restoration when the original violation is <= resto_kappa * violation at entry (IPOPT: 0.9)
   double gap_safety = 10.0;        // safety factor on the barrier duality gap n_v * mu in the local-infeasibility certificate
+  int resto_max_calls = 3, resto_max_iters = 40;   // per instance: entries into the phase and iterations spent inside it; beyond -> Restoration_Failed
   int trig_k = 5; double trig_alpha = 0.05, trig_theta = 0.8;   // early entry: trig_k consecutive accepted steps < trig_alpha with
                                                                 //   theta reduced by less than the factor trig_theta over them
 };
@@ -980,6 +981,7 @@ struct Solver {
   //      stationary point of the l1 violation = LOCAL infeasibility;
   //   MPCB_ST_RESTO_FAILED / MPCB_ST_MAXITER / MPCB_ST_NUMERIC otherwise.
   int restoration() {
+    if (n_resto_calls >= o.resto_max_calls) return MPCB_ST_RESTO_FAILED;     // the phase has been tried often enough on this instance
     ++n_resto_calls;
     const double mu_main = mu;
     // Entry.  The slacks of the general rows (rate, obstacle) are auxiliary variables; after a stalled main phase they lag behind
@@ -1061,6 +1063,7 @@ struct Solver {
         if (Emu(em) <= o.kappa_eps * mu && V > gap + 1e-6 && theta <= 0.01 * V) { rc = MPCB_ST_INFEASIBLE; break; }
       }
       if (iters >= c.max_iter) { rc = MPCB_ST_MAXITER; break; }
+      if (n_resto_iters >= o.resto_max_iters) { rc = MPCB_ST_RESTO_FAILED; break; }   // effort bound of the phase (all its entries together)
       int why = MPCB_ST_RESTO_FAILED;
       if (!ip_iteration(mu_floor, why)) { rc = (why == MPCB_ST_LINESEARCH) ? MPCB_ST_RESTO_FAILED : why; break; }
     }
