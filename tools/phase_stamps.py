@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 out = os.path.join(ROOT, "mpc_motion_planning_amd", "lib", "libmpcbatch_stamps.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-fno-gpu-rdc",
-                       "-DMPCB_STAMPS", "-o", out, os.path.join(ROOT, "mpc_motion_planning_amd", "csrc", "mpcb_api.hip")],
+                       "-DMPCB_STAMPS"] + [a for a in sys.argv[1:] if a.startswith("-D")] + ["-o", out, os.path.join(ROOT, "mpc_motion_planning_amd", "csrc", "mpcb_api.hip")],
                       stderr=subprocess.DEVNULL)
 import mpc_motion_planning_amd._lib as _lib
 _lib.LIB_PATH = out
@@ -15,7 +15,7 @@ from mpc_motion_planning_amd import scenes
 from mpc_motion_planning_amd.solver import BatchSolver, default_config
 
 from mpc_motion_planning_amd import _abi
-if len(sys.argv) > 1 and sys.argv[1] == "dyn":
+if "dyn" in sys.argv[1:]:
     cfg = default_config(model=_abi.MODEL_DYN, N=40, T=0.1, n_obs=3)
     x0, xs, obs = scenes.sample_c4(1, seed=3000, n_obs=3)
     x0, xs = x0[0], xs[0]
