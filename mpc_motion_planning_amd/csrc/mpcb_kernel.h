@@ -92,10 +92,13 @@ enum KinEnt {
 //   Pst [N+1][PST]   P_k (6x6, row-major, slots 0..35), p_k (slots 36..41), a permanent 0.0 (slot 42: unit term of lanes
 //                    without one), pad slot 43 (p stores of non-affine lanes), pad slots 44..47 (P stores of lanes without a
 //                    P entry)
-//   fw  [N+1][FWS]   everything the forward roll-out reads for stage k, contiguous: K (2x6), kff (2), a02 a03 a12 a13 a23 b20,
-//                    d0..d3, then 4 pad slots for the K stores of lanes without a K entry, the stage's step length T_k, one spare
+//   fw  [N+1][FWS]   what the forward roll-out reads for stage k, as six records of FWR doubles, one per component of
+//                    [dX_{k+1}; dU_k]: coefficients of [dX_k; dU_{k-1}] (6), constant, coefficients of dU_k (2), one pad slot.
+//                    Records 0..3 are the rows of [A | d | B] (unit and zero entries written once per solve, a02 a03 a12 a13
+//                    a23 b20 d0..d3 and the stage's step length T_k per iteration), records 4, 5 the gain rows K and kff
+//                    (written by the sweep).  The pad slots take the K stores of lanes without a K entry.
 constexpr int PST = 48, PS_P = 36, PS_ZERO = 42, PS_PADP = 43, PS_PAD = 44;
-constexpr int FWS = 30, FW_KFF = 12, FW_A = 14, FW_D = 20, FW_PAD = 24, FW_T = 28, WSZ = 72, W_ZERO = 64;
+constexpr int FWR = 10, FWS = 62, FW_C0 = 6, FW_B0 = 7, FW_B1 = 8, FW_PAD = 9, WSZ = 136, W_ZERO = 64, W_STAGE = 72;
 // constant block: uniform numbers of the instance that the node-parallel phases read from LDS (one ds_read, short live range)
 // instead of holding ~25 SGPR pairs through the whole solve
 constexpr int CS_WQ = 0, CS_WR = 4, CS_WDR = 6, CS_Q = 8, CS_R = 12, CS_DR = 14, CS_UL = 16, CS_XS = 18, CSZ = 24;
@@ -113,8 +116,8 @@ MPCB_HD Layout layout_kin(int N, int nz, bool resto = false, int nobl = 0) {
   L.ld = N1 | 1;
   int o = 0;
   L.Pst = o; o += N1 * PST;          // first: 16-byte aligned rows for wide LDS reads
-  L.fw = o; o += N1 * FWS;
-  L.W = o; o += WSZ;                 // W^T (8 columns x 6) + 16 pad slots + a permanent 0.0 (W_ZERO)
+  L.fw = o; o += N1 * FWS; o += o & 1;
+  L.W = o; o += WSZ;                 // W^T (8 columns x 6) + 16 pad slots + a permanent 0.0 (W_ZERO) + the staging block of the sweep's tail (64)
   L.cst = o; o += CSZ;
   L.filt = o; o += 2 * FILTER_MAX;
   L.ent = o; o += KIN_NENT * L.ld;
@@ -626,17 +629,30 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   const int pOff = upper ? ei * NA + ej : PS_PAD + (lane & 1), pOffT = upper ? ej * NA + ei : PS_PAD + 2 + (lane & 1);
   const int psOff = (aff && ei < NA) ? PS_P + ei : PS_PADP;
   // gains: lanes (0,j) store K0j, lanes (1,j) store K1j (j < 6); lanes 62 / 63 store the feed-forward terms
-  const int kOff = (ej < NA && ei == 0) ? ej : (ej < NA && ei == 1) ? NA + ej : FW_PAD + (lane & 1);
-  const int kfOff = (lane == 62) ? FW_KFF : (lane == 63) ? FW_KFF + 1 : FW_PAD + 2 + (lane & 1);
+  const int kOff = (ej < NA && ei == 0) ? NX * FWR + ej : (ej < NA && ei == 1) ? (NX + 1) * FWR + ej : FW_PAD + FWR * (lane & 1);
+  const int kfOff = (lane == 62) ? NX * FWR + FW_C0 : (lane == 63) ? (NX + 1) * FWR + FW_C0 : 2 * FWR + FW_PAD + FWR * (lane & 1);
   const bool kRow1 = (ei == 1), kfLane1 = (lane == 63);
+  // staging block of the sweep's tail: rows 6, 7 of M at 0..15, their accumulators at 32..47, the other lanes store into pads
+  const int sOff = lane >= NA * 8 ? lane - NA * 8 : 16 + (lane & 15);
 
   // constant rows of the entry table
   if (isnode) { ent[E_ZERO * ld + k] = 0.0; ent[E_ONE * ld + k] = 1.0; ent[E_T * ld + k] = T; }
   // (Pst slot PS_ZERO = 0.0 is written after the z0 staging below has finished with the aliased region)
 
   double* Pst = lds + L.Pst; double* fw = lds + L.fw;
-  double* Wl = lds + L.W; double* filt = lds + L.filt;
+  double* Wl = lds + L.W; double* filt = lds + L.filt; double* Sl = Wl + W_STAGE;
   if (lane == 0) Wl[W_ZERO] = 0.0;
+  if (isnode) {            // unit and zero entries of the roll-out records (never written again)
+    double* fk = fw + k * FWS;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+#pragma unroll
+      for (int r = 0; r < FWR - 1; ++r) {
+        const bool var = i >= NX ? r <= FW_C0 : (r == FW_C0 || (i == 0 && (r == 2 || r == 3)) || (i == 1 && (r == 2 || r == 3)) || (i == 2 && (r == 3 || r == FW_B0)) || (i == 3 && r == FW_B1));
+        if (!var) fk[i * FWR + r] = (i < NX && r == i) ? 1.0 : 0.0;
+      }
+    }
+  }
   int nfilt = 0;
   double theta_max = 0, theta_min = 0;
   double dw_last = 0.0;
@@ -1004,12 +1020,11 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           for (int i = 0; i < NX; ++i) ent[(E_D0 + i) * ld + k] = dfc[i];
 #pragma unroll
           for (int i = 0; i < NW; ++i) ent[(E_G0 + i) * ld + k] = g[i];
-          double* fk = fw + k * FWS;                     // the same numbers once more, contiguous, for the forward roll-out
-          fk[FW_A + 0] = hasu ? a02 : 0.0; fk[FW_A + 1] = hasu ? a03 : 0.0; fk[FW_A + 2] = hasu ? a12 : 0.0;
-          fk[FW_A + 3] = hasu ? a13 : 0.0; fk[FW_A + 4] = hasu ? a23 : 0.0; fk[FW_A + 5] = hasu ? b20 : 0.0;
+          double* fk = fw + k * FWS;                     // the same numbers once more, as the roll-out's records
+          fk[2] = hasu ? a02 : 0.0; fk[3] = hasu ? a03 : 0.0; fk[FWR + 2] = hasu ? a12 : 0.0; fk[FWR + 3] = hasu ? a13 : 0.0;
+          fk[2 * FWR + 3] = hasu ? a23 : 0.0; fk[2 * FWR + FW_B0] = hasu ? b20 : 0.0; fk[3 * FWR + FW_B1] = T;
 #pragma unroll
-          for (int i = 0; i < NX; ++i) fk[FW_D + i] = dfc[i];
-          fk[FW_T] = T;
+          for (int i = 0; i < NX; ++i) fk[i * FWR + FW_C0] = dfc[i];
           Pst[k * PST + PS_ZERO] = 0.0;
           ent[E_HXY * ld + k] = hxy; ent[E_HPV * ld + k] = hpv; ent[E_HVD * ld + k] = hvd;
           ent[E_H44 * ld + k] = h44; ent[E_H55 * ld + k] = h55; ent[E_H46 * ld + k] = h46; ent[E_H57 * ld + k] = h57;
@@ -1069,12 +1084,16 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           // M = H + [A B]^T W; in the affine lanes the same sum is m = g + [A B]^T q
           const double acc = fma(e.cm[3], Wc[3], fma(e.cm[2], Wc[2], fma(e.cm[1], Wc[1], fma(e.cm[0], Wc[0], e.start)))) + m0;
           const double Mx = aff ? e.hmat : acc;                   // matrix value of this lane (column 4: H itself)
-          // control block Muu (lanes (6,6),(6,7),(7,6),(7,7)) and m_u (affine lanes (6,4),(7,4)) to every lane
-          const double m11 = wv::bcast(Mx, NA * 8 + NA), m12 = wv::bcast(Mx, NA * 8 + NA + 1), m22 = wv::bcast(Mx, (NA + 1) * 8 + NA + 1);
-          const double mu6 = wv::bcast(acc, NA * 8 + 4), mu7 = wv::bcast(acc, (NA + 1) * 8 + 4);
+          // rows 6, 7 of M and the two m_u (accumulator of the affine lanes (6,4), (7,4)) go through a 64-double staging block:
+          // two stores and a handful of reads (five of them wave-uniform) instead of ten v_readlane and eight ds_bpermute
+          Sl[sOff] = Mx; Sl[sOff + 32] = acc;
+          wv::sync();
+          // control block Muu and m_u
+          const double m11 = Sl[NA], m12 = Sl[NA + 1], m22 = Sl[8 + NA + 1];
+          const double mu6 = Sl[32 + 4], mu7 = Sl[32 + 8 + 4];
           // rows 6,7 of M at column j and at column i (M is symmetric up to rounding)
-          const double M6j = wv::shfl(Mx, NA * 8 + ej), M7j = wv::shfl(Mx, (NA + 1) * 8 + ej);
-          const double M6i = wv::shfl(Mx, NA * 8 + ei), M7i = wv::shfl(Mx, (NA + 1) * 8 + ei);
+          const double M6j = Sl[ej], M7j = Sl[8 + ej];
+          const double M6i = Sl[ei], M7i = Sl[8 + ei];
           // e is spent.  Prefetch for the next stage behind the exchanges of this one: the DS queue is in order, so these 10
           // reads must not sit in front of the W / M traffic of the recursion (index -1 after stage 0 reads the tail of the
           // filter region: in bounds, never used)
@@ -1133,41 +1152,49 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       if (!fact_ok) { status = MPCB_ST_NUMERIC; break; }
 
       MPCB_STAMP(t_c);
-      // ----- forward roll-out of the step: every lane carries the same 6-vector, lane k latches its node ----------
+      // ----- forward roll-out of the step: lane i < 6 advances component i of [dX_s; dU_{s-1}] ---------------------
+      // One stage is  t_i = c_i0 + sum_r C_ir v_r  (rows 0..3: the A part of the state update plus the defect, rows 4, 5: the gain
+      // rows, t = dU_s), then  n_i = t_i + b_i0 dU_s[0] + b_i1 dU_s[1]  (the B part: b20 in row 2, T_s in row 3).  The six numbers
+      // of v travel through scalar registers (v_readlane); a lane reads the nine numbers of its own record of the stage's fw row
+      // instead of every lane reading the whole row, and the steps are written to the rows of the (spent) condensed gradient, [component][node], where lane k picks up its node's.
       double dX[NX] = {0, 0, 0, 0}, dU[NU] = {0, 0};
       {
-        // 24 table values per stage, none of them on the recursion: prefetched one stage ahead (ping-pong registers)
-        struct FwEnt { double K[2 * NA], kf0, kf1, a02, a03, a12, a13, a23, b20, d0, d1, d2, d3, Ts; };
-        auto load_fw = [&](int s, FwEnt& f) {
-          const double* q = fw + s * FWS;                // 24 contiguous doubles, uniform address: wide LDS reads
+        const int li = lane < NA ? lane : 0;
+        // rows 0..3 hold dX_{s+1}, rows 4, 5 hold dU_s; the other lanes store into the two remaining (equally spent) gradient rows,
+        // so that the store needs no EXEC change
+        double* hist = ent + (E_G0 + (lane < NA ? lane : NA + (lane & 1))) * ld + (lane < NX ? 1 : 0);
+        if (lane < NX) hist[-1] = 0.0;                                   // dX_0 = 0 (X_0 is pinned)
+        struct FwRec { double c[NA], c0, b0, b1; };
+        auto load_fw = [&](int s, FwRec& f) {
+          const double* q = fw + s * FWS + li * FWR;      // one address, nine immediates
 #pragma unroll
-          for (int r = 0; r < 2 * NA; ++r) f.K[r] = q[r];
-          f.kf0 = q[FW_KFF]; f.kf1 = q[FW_KFF + 1];
-          f.a02 = q[FW_A]; f.a03 = q[FW_A + 1]; f.a12 = q[FW_A + 2]; f.a13 = q[FW_A + 3]; f.a23 = q[FW_A + 4]; f.b20 = q[FW_A + 5];
-          f.d0 = q[FW_D]; f.d1 = q[FW_D + 1]; f.d2 = q[FW_D + 2]; f.d3 = q[FW_D + 3]; f.Ts = q[FW_T];
+          for (int r = 0; r < NA; ++r) f.c[r] = q[r];
+          f.c0 = q[FW_C0]; f.b0 = q[FW_B0]; f.b1 = q[FW_B1];
         };
-        double dx0 = 0, dx1 = 0, dx2 = 0, dx3 = 0, dx4 = 0, dx5 = 0;
-        auto fstage = [&](int s, const FwEnt& f, FwEnt& nxt) {
-          load_fw(s + 1 < N ? s + 1 : s, nxt);
+        double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;           // wave-uniform
+        auto fstage = [&](int s, const FwRec& f, FwRec& nxt) {
+          load_fw(s + 1, nxt);                             // (row N exists and holds finite numbers; its record is never used)
           MPCB_SCHED_FENCE();
-          const double du0 = fma(f.K[5], dx5, fma(f.K[4], dx4, fma(f.K[3], dx3, fma(f.K[2], dx2, fma(f.K[1], dx1, fma(f.K[0], dx0, f.kf0))))));
-          const double du1 = fma(f.K[11], dx5, fma(f.K[10], dx4, fma(f.K[9], dx3, fma(f.K[8], dx2, fma(f.K[7], dx1, fma(f.K[6], dx0, f.kf1))))));
-          const double n0 = fma(f.a03, dx3, fma(f.a02, dx2, dx0 + f.d0));
-          const double n1 = fma(f.a13, dx3, fma(f.a12, dx2, dx1 + f.d1));
-          const double n2 = fma(f.b20, du0, fma(f.a23, dx3, dx2 + f.d2));
-          const double n3 = fma(f.Ts, du1, dx3 + f.d3);
-          if (k == s) { dU[0] = du0; dU[1] = du1; }
-          if (k == s + 1) { dX[0] = n0; dX[1] = n1; dX[2] = n2; dX[3] = n3; }
-          dx0 = n0; dx1 = n1; dx2 = n2; dx3 = n3; dx4 = du0; dx5 = du1;
+          const double t = fma(f.c[5], v5, fma(f.c[4], v4, fma(f.c[3], v3, fma(f.c[2], v2, fma(f.c[1], v1, fma(f.c[0], v0, f.c0))))));
+          const double du0 = wv::bcast(t, NX), du1 = wv::bcast(t, NX + 1);
+          const double n = fma(f.b1, du1, fma(f.b0, du0, t));
+          hist[s] = n;
+          v0 = wv::bcast(n, 0); v1 = wv::bcast(n, 1); v2 = wv::bcast(n, 2); v3 = wv::bcast(n, 3); v4 = du0; v5 = du1;
         };
         {
-          FwEnt fA, fB;
+          FwRec fA, fB;
           load_fw(0, fA);
           int s = 0;
 #pragma clang loop unroll(disable)
           for (; s + 1 < N; s += 2) { fstage(s, fA, fB); fstage(s + 1, fB, fA); }
           if (s < N) fstage(s, fA, fB);
         }
+        wv::sync();
+        if (isnode) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) dX[i] = ent[(E_G0 + i) * ld + k];
+        }
+        if (hasu) { dU[0] = ent[(E_G0 + NX) * ld + k]; dU[1] = ent[(E_G0 + NX + 1) * ld + k]; }
       }
       const double dUp0 = wv::shfl(dU[0], k - 1), dUp1 = wv::shfl(dU[1], k - 1);   // dU_{k-1}
       // costate of the full step: lamF_k = P_k [dX_k; dU_{k-1}] + p_k  (node-parallel)
