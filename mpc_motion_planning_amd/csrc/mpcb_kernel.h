@@ -632,15 +632,14 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   const int kOff = (ej < NA && ei == 0) ? NX * FWR + ej : (ej < NA && ei == 1) ? (NX + 1) * FWR + ej : FW_PAD + FWR * (lane & 1);
   const int kfOff = (lane == 62) ? NX * FWR + FW_C0 : (lane == 63) ? (NX + 1) * FWR + FW_C0 : 2 * FWR + FW_PAD + FWR * (lane & 1);
   const bool kRow1 = (ei == 1), kfLane1 = (lane == 63);
-  // staging block of the sweep's tail: rows 6, 7 of M at 0..15, their accumulators at 32..47, the other lanes store into pads
-  const int sOff = lane >= NA * 8 ? lane - NA * 8 : 16 + (lane & 15);
 
   // constant rows of the entry table
   if (isnode) { ent[E_ZERO * ld + k] = 0.0; ent[E_ONE * ld + k] = 1.0; ent[E_T * ld + k] = T; }
   // (Pst slot PS_ZERO = 0.0 is written after the z0 staging below has finished with the aliased region)
 
   double* Pst = lds + L.Pst; double* fw = lds + L.fw;
-  double* Wl = lds + L.W; double* filt = lds + L.filt; double* Sl = Wl + W_STAGE;
+  double* Wl = (double*)__builtin_assume_aligned(lds + L.W, 16); double* filt = lds + L.filt;
+  double* Sl = (double*)__builtin_assume_aligned(Wl + W_STAGE, 16);
   if (lane == 0) Wl[W_ZERO] = 0.0;
   if (isnode) {            // unit and zero entries of the roll-out records (never written again)
     double* fk = fw + k * FWS;
@@ -1051,6 +1050,9 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         // into the SAME registers as soon as the running stage has spent them (no second set), so that only the P+ row and
         // the W exchange sit on the critical path.  MPCB_SCHED_FENCE keeps the compiler from sinking the batched loads next
         // to their uses.
+        // staging block of the sweep's tail: rows 6, 7 of M interleaved at 0..15 (M6j at 2j, M7j at 2j+1), their accumulators likewise at
+        // 32..47, the other lanes store into pads
+        const int sOff = lane >= NA * 8 ? 2 * ej + (ei - NA) : 16 + (lane & 15);
         struct StageEnt { double cw[NX], cm[NX], start, hmat; };
         auto load_ent = [&](int s, StageEnt& e) {
 #pragma unroll
@@ -1084,16 +1086,17 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           // M = H + [A B]^T W; in the affine lanes the same sum is m = g + [A B]^T q
           const double acc = fma(e.cm[3], Wc[3], fma(e.cm[2], Wc[2], fma(e.cm[1], Wc[1], fma(e.cm[0], Wc[0], e.start)))) + m0;
           const double Mx = aff ? e.hmat : acc;                   // matrix value of this lane (column 4: H itself)
-          // rows 6, 7 of M and the two m_u (accumulator of the affine lanes (6,4), (7,4)) go through a 64-double staging block:
-          // two stores and a handful of reads (five of them wave-uniform) instead of ten v_readlane and eight ds_bpermute
+          // rows 6, 7 of M and the two m_u (accumulator of the affine lanes (6,4), (7,4)) go through a 64-double staging block,
+          // rows interleaved ({M6j, M7j} adjacent): two stores and five 16-byte reads (three of them wave-uniform) instead of ten
+          // v_readlane and eight ds_bpermute
           Sl[sOff] = Mx; Sl[sOff + 32] = acc;
           wv::sync();
           // control block Muu and m_u
-          const double m11 = Sl[NA], m12 = Sl[NA + 1], m22 = Sl[8 + NA + 1];
-          const double mu6 = Sl[32 + 4], mu7 = Sl[32 + 8 + 4];
+          const double m11 = Sl[2 * NA], m12 = Sl[2 * (NA + 1)], m22 = Sl[2 * (NA + 1) + 1];
+          const double mu6 = Sl[32 + 2 * 4], mu7 = Sl[32 + 2 * 4 + 1];
           // rows 6,7 of M at column j and at column i (M is symmetric up to rounding)
-          const double M6j = Sl[ej], M7j = Sl[8 + ej];
-          const double M6i = Sl[ei], M7i = Sl[8 + ei];
+          const double M6j = Sl[2 * ej], M7j = Sl[2 * ej + 1];
+          const double M6i = Sl[2 * ei], M7i = Sl[2 * ei + 1];
           // e is spent.  Prefetch for the next stage behind the exchanges of this one: the DS queue is in order, so these 10
           // reads must not sit in front of the W / M traffic of the recursion (index -1 after stage 0 reads the tail of the
           // filter region: in bounds, never used)
@@ -1159,10 +1162,11 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       // instead of every lane reading the whole row, and the steps are written to the rows of the (spent) condensed gradient, [component][node], where lane k picks up its node's.
       double dX[NX] = {0, 0, 0, 0}, dU[NU] = {0, 0};
       {
-        const int li = lane < NA ? lane : 0;
+        const int lq = wv::opaque(lane);                 // (addresses re-formed per iteration instead of staying live — and spilled — through the solve)
+        const int li = lq < NA ? lq : 0;
         // rows 0..3 hold dX_{s+1}, rows 4, 5 hold dU_s; the other lanes store into the two remaining (equally spent) gradient rows,
         // so that the store needs no EXEC change
-        double* hist = ent + (E_G0 + (lane < NA ? lane : NA + (lane & 1))) * ld + (lane < NX ? 1 : 0);
+        double* hist = ent + (E_G0 + (lq < NA ? lq : NA + (lq & 1))) * ld + (lq < NX ? 1 : 0);
         if (lane < NX) hist[-1] = 0.0;                                   // dX_0 = 0 (X_0 is pinned)
         struct FwRec { double c[NA], c0, b0, b1; };
         auto load_fw = [&](int s, FwRec& f) {

@@ -20,10 +20,7 @@
 namespace mpcbk {
 
 enum DynEnt {
-  DE_ZERO = 0, DE_ONE, DE_T,
-  DE_A02, DE_A03, DE_A04, DE_A12, DE_A13, DE_A14, DE_A34, DE_A35, DE_A43, DE_A44, DE_A45, DE_A53, DE_A54, DE_A55,
-  DE_B4, DE_B5,
-  DE_D0, DE_D1, DE_D2, DE_D3, DE_D4, DE_D5,
+  DE_ZERO = 0, DE_ONE,                 // (the entries of [A B], the defect and the step length live in the fw rows only)
   DE_G0, DE_G1, DE_G2, DE_G3, DE_G4, DE_G5, DE_G6, DE_G7, DE_G8, DE_G9,
   DE_H00, DE_H01, DE_H11, DE_H22, DE_H23, DE_H24, DE_H33, DE_H34, DE_H35, DE_H44, DE_H45, DE_H55,
   DE_H38, DE_H48, DE_H58, DE_H88, DE_H99, DE_H66, DE_H77, DE_H68, DE_H79,
@@ -32,8 +29,9 @@ enum DynEnt {
 
 // LDS layout (doubles):
 //   Pst [N+1][66]  P_k (8x8) + 2 pad   pst [N+1][10]  p_k (8), slot 8 = permanent 0.0, slot 9 pad
-//   fw  [N+1][DFWS] per-stage numbers of the forward roll-out, contiguous: K (2x8), kff (2), the 14 A entries, b4 b5, d (6), pad
-constexpr int DPST = 66 /* P_k 8x8 + 2 pad slots for the stores of the lanes below the diagonal */, DPSS = 10, DFWS = 46, DFW_KFF = 16, DFW_A = 18, DFW_B = 32, DFW_D = 34, DFW_PAD = 40, DFW_T = 44, DWSZ = 64, DWU = 16 + 16;
+//   fw  [N+1][DFWS] per-stage numbers, [node][slot]: K (2x8), kff (2), the 14 A entries, b4 b5, d (6), 2 pad slots, 1.0, 0.0, T_k, a spare.  Read by the forward roll-out (whole row) AND by the sweep (each lane its own slots of [A B | d]): the
+//                   single copy keeps the N = 40 instance at 53 KB, three workgroups per CU instead of two
+constexpr int DPST = 66 /* P_k 8x8 + 2 pad slots for the stores of the lanes below the diagonal */, DPSS = 10, DFWS = 46, DFW_KFF = 16, DFW_A = 18, DFW_B = 32, DFW_D = 34, DFW_PAD = 40, DFW_ONE = 42, DFW_ZERO = 43, DFW_T = 44, DWSZ = 64, DWU = 16 + 16;
 // constant block (as in the kin kernel): cost weights, reference state and last control, read from LDS by the node-parallel phases
 constexpr int DCS_WQ = 0, DCS_WR = 6, DCS_WDR = 8, DCS_Q = 10, DCS_R = 16, DCS_DR = 18, DCS_UL = 20, DCS_XS = 22, DCSZ = 28;
 // per-node cost table of the RESTO instantiation, [row][64] (see CostRow in mpcb_kernel.h)
@@ -440,21 +438,22 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   }
 
   // ----- Riccati lane constants: lane = entry (i,j) of the 8x8 state block [X, U_prev]; the control rows ride along ---------------------------------
+  // slot of entry (r, col) of [A B] inside the stage's fw row; a[] = {a02,a03,a04, a12,a13,a14, a34,a35, a43,a44,a45, a53,a54,a55}
   auto slotAB = [&](int r, int col) -> int {
     if (r < NX) {
       if (col < NX) {
-        if (r == 0) return col == 0 ? DE_ONE : col == 2 ? DE_A02 : col == 3 ? DE_A03 : col == 4 ? DE_A04 : DE_ZERO;
-        if (r == 1) return col == 1 ? DE_ONE : col == 2 ? DE_A12 : col == 3 ? DE_A13 : col == 4 ? DE_A14 : DE_ZERO;
-        if (r == 2) return col == 2 ? DE_ONE : col == 5 ? DE_T : DE_ZERO;
-        if (r == 3) return col == 3 ? DE_ONE : col == 4 ? DE_A34 : col == 5 ? DE_A35 : DE_ZERO;
-        if (r == 4) return col == 3 ? DE_A43 : col == 4 ? DE_A44 : col == 5 ? DE_A45 : DE_ZERO;
-        return col == 3 ? DE_A53 : col == 4 ? DE_A54 : col == 5 ? DE_A55 : DE_ZERO;
+        if (r == 0) return col == 0 ? DFW_ONE : col == 2 ? DFW_A + 0 : col == 3 ? DFW_A + 1 : col == 4 ? DFW_A + 2 : DFW_ZERO;
+        if (r == 1) return col == 1 ? DFW_ONE : col == 2 ? DFW_A + 3 : col == 3 ? DFW_A + 4 : col == 4 ? DFW_A + 5 : DFW_ZERO;
+        if (r == 2) return col == 2 ? DFW_ONE : col == 5 ? DFW_T : DFW_ZERO;
+        if (r == 3) return col == 3 ? DFW_ONE : col == 4 ? DFW_A + 6 : col == 5 ? DFW_A + 7 : DFW_ZERO;
+        if (r == 4) return col == 3 ? DFW_A + 8 : col == 4 ? DFW_A + 9 : col == 5 ? DFW_A + 10 : DFW_ZERO;
+        return col == 3 ? DFW_A + 11 : col == 4 ? DFW_A + 12 : col == 5 ? DFW_A + 13 : DFW_ZERO;
       }
-      if (col == 8) return r == 4 ? DE_B4 : r == 5 ? DE_B5 : DE_ZERO;
-      if (col == 9) return r == 3 ? DE_T : DE_ZERO;
-      return DE_ZERO;
+      if (col == 8) return r == 4 ? DFW_B : r == 5 ? DFW_B + 1 : DFW_ZERO;
+      if (col == 9) return r == 3 ? DFW_T : DFW_ZERO;
+      return DFW_ZERO;
     }
-    return (col == r + 2) ? DE_ONE : DE_ZERO;
+    return (col == r + 2) ? DFW_ONE : DFW_ZERO;
   };
   auto slotH = [&](int r, int col) -> int {
     const int lo = r < col ? r : col, hi = r < col ? col : r;
@@ -479,8 +478,8 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   int sABj[NX], sABi[NX];
 #pragma unroll
   for (int r = 0; r < NX; ++r) {
-    sABj[r] = (aff ? DE_D0 + r : slotAB(r, ej)) * ld;
-    sABi[r] = slotAB(r, ei) * ld;
+    sABj[r] = aff ? DFW_D + r : slotAB(r, ej);
+    sABi[r] = slotAB(r, ei);
   }
   const int sHij = slotH(ei, ej) * ld;
   const int sStart = (aff ? DE_G0 + ei : slotH(ei, ej)) * ld;
@@ -492,10 +491,11 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   const int psOff = aff ? ei : 9;
   // gains: lanes (0,j) store K0j, lanes (1,j) store K1j; lanes 62 / 63 store the feed-forward terms; pad slots elsewhere
   const int kOff = (ei == 0) ? ej : (ei == 1) ? NA + ej : DFW_PAD + (lane & 1);
-  const int kfOff = (lane == 62) ? DFW_KFF : (lane == 63) ? DFW_KFF + 1 : DFW_PAD + 2 + (lane & 1);
+  const int kfOff = (lane == 62) ? DFW_KFF : (lane == 63) ? DFW_KFF + 1 : DFW_PAD + (lane & 1);
   const bool kRow1 = (ei == 1), kfLane1 = (lane == 63);
+  const int sOff = lane >= 48 ? 2 * ej + cU : 16 + (lane & 15);      // staging of the sweep's tail: lanes of rows 6,7 at 2j + c, pads elsewhere
   const int pOff = ei <= ej ? ei * NA + ej : NA * NA, pOffT = ei <= ej ? ej * NA + ei : NA * NA + 1;
-  if (isnode) { ent[DE_ZERO * ld + k] = 0.0; ent[DE_ONE * ld + k] = 1.0; ent[DE_T * ld + k] = T; }
+  if (isnode) { ent[DE_ZERO * ld + k] = 0.0; ent[DE_ONE * ld + k] = 1.0; }
 
   double* Pst = lds + L.Pst; double* pst = lds + L.pst; double* fw = lds + L.fw;
   double* Wl = lds + L.W; double* WuL = lds + L.Wu; double* filt = lds + L.filt;
@@ -842,14 +842,6 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         }
         if (isnode) {
           const double z = hasu ? 1.0 : 0.0;
-          ent[DE_A02 * ld + k] = z * J.a02; ent[DE_A03 * ld + k] = z * J.a03; ent[DE_A04 * ld + k] = z * J.a04;
-          ent[DE_A12 * ld + k] = z * J.a12; ent[DE_A13 * ld + k] = z * J.a13; ent[DE_A14 * ld + k] = z * J.a14;
-          ent[DE_A34 * ld + k] = z * J.a34; ent[DE_A35 * ld + k] = z * J.a35;
-          ent[DE_A43 * ld + k] = z * J.a43; ent[DE_A44 * ld + k] = z * J.a44; ent[DE_A45 * ld + k] = z * J.a45;
-          ent[DE_A53 * ld + k] = z * J.a53; ent[DE_A54 * ld + k] = z * J.a54; ent[DE_A55 * ld + k] = z * J.a55;
-          ent[DE_B4 * ld + k] = z * J.b4; ent[DE_B5 * ld + k] = z * J.b5;
-#pragma unroll
-          for (int i = 0; i < NX; ++i) ent[(DE_D0 + i) * ld + k] = dfc[i];
 #pragma unroll
           for (int i = 0; i < NW; ++i) ent[(DE_G0 + i) * ld + k] = g[i];
           double* fk = fw + k * DFWS;
@@ -859,7 +851,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           fk[DFW_B] = z * J.b4; fk[DFW_B + 1] = z * J.b5;
 #pragma unroll
           for (int i = 0; i < NX; ++i) fk[DFW_D + i] = dfc[i];
-          fk[DFW_T] = T;
+          fk[DFW_T] = T; fk[DFW_ZERO] = 0.0; fk[DFW_ONE] = 1.0;
           pst[k * DPSS + 8] = 0.0;
           ent[DE_H01 * ld + k] = h01; ent[DE_H23 * ld + k] = Hh.h23; ent[DE_H24 * ld + k] = Hh.h24;
           ent[DE_H34 * ld + k] = Hh.h34; ent[DE_H35 * ld + k] = Hh.h35; ent[DE_H45 * ld + k] = Hh.h45;
@@ -886,11 +878,12 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         wv::sync();
         struct StageEnt { double abj[NX], abi[NX], start, hmat, startU, hU, startUU, b4, b5, Ts; };
         auto load_ent = [&](int s, StageEnt& e) {
+          const double* fs = fw + s * DFWS;              // [A B | d], T: the stage's fw row, each lane its own slots
 #pragma unroll
-          for (int r = 0; r < NX; ++r) { e.abj[r] = ent[sABj[r] + s]; e.abi[r] = ent[sABi[r] + s]; }
+          for (int r = 0; r < NX; ++r) { e.abj[r] = fs[sABj[r]]; e.abi[r] = fs[sABi[r]]; }
           e.start = ent[sStart + s]; e.hmat = ent[sHij + s];
           e.startU = ent[sStartU + s]; e.hU = ent[sHU + s]; e.startUU = ent[sStartUU + s];
-          e.b4 = ent[DE_B4 * ld + s]; e.b5 = ent[DE_B5 * ld + s]; e.Ts = ent[DE_T * ld + s];
+          e.b4 = fs[DFW_B]; e.b5 = fs[DFW_B + 1]; e.Ts = fs[DFW_T];
         };
         auto stage = [&](int s) -> bool {
           StageEnt e; load_ent(s, e);
@@ -920,10 +913,15 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           const double muu = e.startUU + (cU ? fma(e.Ts, Wuc[3], Wuc[7]) : fma(e.b4, Wuc[4], fma(e.b5, Wuc[5], Wuc[6])));
           const double Mx = aff ? e.hmat : acc;
           const double MxU = aff ? e.hU : mux;
-          const double m11 = wv::bcast(muu, 48), m12 = wv::bcast(muu, 49), m22 = wv::bcast(muu, 57);
-          const double mu8 = wv::bcast(mux, 54), mu9 = wv::bcast(mux, 62);
-          const double M8j = wv::shfl(MxU, 48 + ej), M9j = wv::shfl(MxU, 56 + ej);
-          const double M8i = wv::shfl(MxU, 48 + ei), M9i = wv::shfl(MxU, 56 + ei);
+          // the control rows of M, M_uu and m_u go to every lane through a staging block that aliases W^T / W_u^T (both spent):
+          // three stores and five 16-byte reads instead of ten v_readlane and eight ds_bpermute.  Rows interleaved: (c, j) at 2j + c
+          wv::sync();                                    // every lane has read its W column
+          Wl[sOff] = MxU; Wl[sOff + 32] = muu; Wl[sOff + 64] = mux;
+          wv::sync();
+          const double m11 = Wl[32], m12 = Wl[32 + 2], m22 = Wl[32 + 3];
+          const double mu8 = Wl[64 + 12], mu9 = Wl[64 + 13];
+          const double M8j = Wl[2 * ej], M9j = Wl[2 * ej + 1];
+          const double M8i = Wl[2 * ei], M9i = Wl[2 * ei + 1];
           const double det = m11 * m22 - m12 * m12, dmar = det - 1e-14 * m11 * m22;
           const bool okpd = (m11 > 0) & (dmar > 0) & (dmar < 1e300);                    // wave-uniform; false for NaN / inf
           const double idet = wv::rcp(det);
@@ -953,43 +951,55 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       if (!fact_ok) { status = MPCB_ST_NUMERIC; break; }
 
       MPCB_STAMP(t_c);
-      // ----- forward roll-out of the step (per-stage numbers contiguous in fw, prefetched one stage ahead) -----------
+      // ----- forward roll-out of the step: lane i < 8 advances component i of [dX_s; dU_{s-1}] (see the kinematic kernel) ---------
+      // t_i = c_i + sum_r C_ir v_r (rows 0..5: the A part and the defect, rows 6, 7: the gain rows, t = dU_s), n_i = t_i + b_i0 dU_s[0] +
+      // b_i1 dU_s[1].  v travels through scalar registers; a lane reads its eleven numbers at its own slots of the stage's fw row;
+      // the steps go to the rows of the spent condensed gradient, [component][node].
       double dX[NX] = {0, 0, 0, 0, 0, 0}, dU[NU] = {0, 0};
       {
-        struct FwEnt { double K[2 * NA], kf0, kf1, a[14], b4, b5, d[NX], Ts; };
-        auto load_fw = [&](int s, FwEnt& f) {
+        const int lq = wv::opaque(lane);               // (re-formed per iteration: the offsets must not stay live through the solve)
+        const int li = lq < NA ? lq : 0;
+        int fo[NA + 3];
+#pragma unroll
+        for (int r = 0; r < NA; ++r) fo[r] = li < NX ? slotAB(li, r) : (li - NX) * NA + r;
+        fo[NA] = li < NX ? DFW_D + li : DFW_KFF + (li - NX);
+        fo[NA + 1] = li < NX ? slotAB(li, 8) : DFW_ZERO;
+        fo[NA + 2] = li < NX ? slotAB(li, 9) : DFW_ZERO;
+        // rows 0..5 hold dX_{s+1}, rows 6, 7 hold dU_s; the other lanes store into the two remaining gradient rows
+        double* hist = ent + (DE_G0 + (lq < NA ? lq : NA + (lq & 1))) * ld + (lq < NX ? 1 : 0);
+        if (lane < NX) hist[-1] = 0.0;                 // dX_0 = 0 (X_0 is pinned)
+        struct FwRec { double c[NA], c0, b0, b1; };
+        auto load_fw = [&](int s, FwRec& f) {
           const double* q = fw + s * DFWS;
 #pragma unroll
-          for (int r = 0; r < 2 * NA; ++r) f.K[r] = q[r];
-          f.kf0 = q[DFW_KFF]; f.kf1 = q[DFW_KFF + 1];
-#pragma unroll
-          for (int r = 0; r < 14; ++r) f.a[r] = q[DFW_A + r];
-          f.b4 = q[DFW_B]; f.b5 = q[DFW_B + 1];
-#pragma unroll
-          for (int r = 0; r < NX; ++r) f.d[r] = q[DFW_D + r];
-          f.Ts = q[DFW_T];
+          for (int r = 0; r < NA; ++r) f.c[r] = q[fo[r]];
+          f.c0 = q[fo[NA]]; f.b0 = q[fo[NA + 1]]; f.b1 = q[fo[NA + 2]];
         };
-        double dx[NA] = {0, 0, 0, 0, 0, 0, 0, 0};
-        auto fstage = [&](int s, const FwEnt& f) {
+        double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0;      // wave-uniform
+        auto fstage = [&](int s, const FwRec& f, FwRec& nxt) {
+          load_fw(s + 1, nxt);                         // (row N exists and holds finite numbers; its values are never used)
           MPCB_SCHED_FENCE();
-          const double du0 = f.kf0 + ((f.K[0] * dx[0] + f.K[1] * dx[1]) + (f.K[2] * dx[2] + f.K[3] * dx[3])) +
-                             ((f.K[4] * dx[4] + f.K[5] * dx[5]) + (f.K[6] * dx[6] + f.K[7] * dx[7]));
-          const double du1 = f.kf1 + ((f.K[8] * dx[0] + f.K[9] * dx[1]) + (f.K[10] * dx[2] + f.K[11] * dx[3])) +
-                             ((f.K[12] * dx[4] + f.K[13] * dx[5]) + (f.K[14] * dx[6] + f.K[15] * dx[7]));
-          // a[] = {a02,a03,a04, a12,a13,a14, a34,a35, a43,a44,a45, a53,a54,a55}
-          const double n0 = dx[0] + f.a[0] * dx[2] + f.a[1] * dx[3] + f.a[2] * dx[4] + f.d[0];
-          const double n1 = dx[1] + f.a[3] * dx[2] + f.a[4] * dx[3] + f.a[5] * dx[4] + f.d[1];
-          const double n2 = dx[2] + f.Ts * dx[5] + f.d[2];
-          const double n3 = dx[3] + f.a[6] * dx[4] + f.a[7] * dx[5] + f.Ts * du1 + f.d[3];
-          const double n4 = f.a[8] * dx[3] + f.a[9] * dx[4] + f.a[10] * dx[5] + f.b4 * du0 + f.d[4];
-          const double n5 = f.a[11] * dx[3] + f.a[12] * dx[4] + f.a[13] * dx[5] + f.b5 * du0 + f.d[5];
-          if (k == s) { dU[0] = du0; dU[1] = du1; }
-          if (k == s + 1) { dX[0] = n0; dX[1] = n1; dX[2] = n2; dX[3] = n3; dX[4] = n4; dX[5] = n5; }
-          dx[0] = n0; dx[1] = n1; dx[2] = n2; dx[3] = n3; dx[4] = n4; dx[5] = n5; dx[6] = du0; dx[7] = du1;
+          const double t = fma(f.c[7], v7, fma(f.c[6], v6, fma(f.c[5], v5, fma(f.c[4], v4, fma(f.c[3], v3, fma(f.c[2], v2, fma(f.c[1], v1, fma(f.c[0], v0, f.c0))))))));
+          const double du0 = wv::bcast(t, NX), du1 = wv::bcast(t, NX + 1);
+          const double n = fma(f.b1, du1, fma(f.b0, du0, t));
+          hist[s] = n;
+          v0 = wv::bcast(n, 0); v1 = wv::bcast(n, 1); v2 = wv::bcast(n, 2); v3 = wv::bcast(n, 3); v4 = wv::bcast(n, 4); v5 = wv::bcast(n, 5);
+          v6 = du0; v7 = du1;
         };
-        // one register set only (40 doubles): the dyn kernel is register-bound, a second prefetch set would spill
+        {
+          FwRec fA, fB;
+          load_fw(0, fA);
+          int s = 0;
 #pragma clang loop unroll(disable)
-        for (int s = 0; s < N; ++s) { FwEnt f; load_fw(s, f); fstage(s, f); }
+          for (; s + 1 < N; s += 2) { fstage(s, fA, fB); fstage(s + 1, fB, fA); }
+          if (s < N) fstage(s, fA, fB);
+        }
+        wv::sync();
+        if (isnode) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) dX[i] = ent[(DE_G0 + i) * ld + k];
+        }
+        if (hasu) { dU[0] = ent[(DE_G0 + NX) * ld + k]; dU[1] = ent[(DE_G0 + NX + 1) * ld + k]; }
       }
       const double dUp0 = wv::shfl(dU[0], k - 1), dUp1 = wv::shfl(dU[1], k - 1);
       double lamF[NX] = {0, 0, 0, 0, 0, 0};

@@ -12,7 +12,10 @@
 #ifndef MPCB_WAVE_EMU
 #include <hip/hip_runtime.h>
 #define MPCB_DEV __device__ __forceinline__
-#define MPCB_DEVFN __device__
+// the solve functions are ALWAYS inlined into their kernels: out of line (hipcc 7.2 does that to the five largest instantiations on its
+// own) the LDS pointer becomes a generic pointer, every LDS access a FLAT instruction, and the restoration pass of kin<8, GEN> then
+// computed wrong costates on the GPU (tools/probe_fuzzcase.py 11 4) while the same source stepped on the CPU was right
+#define MPCB_DEVFN __device__ __forceinline__
 #define MPCB_HD __host__ __device__ inline
 
 namespace wv {

@@ -9,6 +9,8 @@
 #include "../../mpc_motion_planning_amd/csrc/mpcb_kernel_dyn.h"
 
 #include <thread>
+#include <limits>
+#include <cstdlib>
 #include <vector>
 
 namespace wv {
@@ -22,7 +24,9 @@ static void run_instance(const MpcbKArgs& a, int b) {
   const bool dyn = a.cfg.model == MPCB_MODEL_DYN;
   const bool rp = a.pass == 1;                                    // restoration pass: the RESTO instantiations
   const int total = dyn ? layout_dyn(a.cfg.N, rp, obs_in_lds(NOBS)).total : layout_kin(a.cfg.N, a.nz, rp, obs_in_lds(NOBS)).total;
-  std::vector<double> lds(total + 64, 0.0);
+  // LDS starts as garbage on the device: poison it here (MPCB_EMU_LDS_FILL, default NaN), so that a read of a never-written slot shows
+  const char* fill_env = std::getenv("MPCB_EMU_LDS_FILL");
+  std::vector<double> lds(total + 64, fill_env ? std::atof(fill_env) : std::numeric_limits<double>::quiet_NaN());
   std::barrier<> bar(64);
   wv::Emu emu; emu.bar = &bar;
   std::vector<std::thread> th;
