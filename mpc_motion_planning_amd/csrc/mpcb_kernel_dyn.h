@@ -1077,10 +1077,14 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         a_du = wv::uni((r2 > tau) ? tau / r2 : 1.0);
       }
       const double phi0 = wv::uni(osc * fval - mu * logsum), th0 = theta;
+      // theta^s_theta and (-dphi)^s_phi of the switching condition: once per iteration (a_min and every trial of the line search use them)
+      const bool sw_on = th0 <= theta_min && dphi < 0;
+      double pw_th = 0.0, pw_dp = 1.0;
+      if (sw_on) { pw_th = pow(th0, S_THETA); pw_dp = pow(-dphi, S_PHI); }
       double a_min;
       if (dphi < 0) {
         a_min = fmin(G_THETA, G_PHI * th0 / (-dphi));
-        if (th0 <= theta_min) a_min = fmin(a_min, DELTA * pow(th0, S_THETA) / pow(-dphi, S_PHI));
+        if (sw_on) a_min = fmin(a_min, DELTA * pw_th / pw_dp);
       } else a_min = G_THETA;
       a_min = wv::uni(a_min * G_ALPHA);
 
@@ -1115,7 +1119,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           for (int e = lane; e < nfilt; e += 64) if (tht >= filt[2 * e] && phit >= filt[2 * e + 1]) fok = false;
           if (wv::all(fok)) {
             bool sw = false;
-            if (th0 <= theta_min && dphi < 0) sw = alpha * pow(-dphi, S_PHI) > DELTA * pow(th0, S_THETA);
+            if (sw_on) sw = alpha * pw_dp > DELTA * pw_th;
             if (th0 <= theta_min && sw) {
               // IPOPT's Compare_le(lhs, rhs, base): lhs - rhs <= 10 eps |base| — round-off slack on both acceptance tests
               // (ArmijoHolds / IsAcceptableToCurrentIterate in IpFilterLSAcceptor.cpp)
@@ -1161,12 +1165,14 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       }
 
       recips();
+      // safeguard of the duals (IPOPT kappa_sigma): v within [mu / (kappa s), kappa mu / s]; the two scalars once, a multiplication per item
+      const double mu_hi = K_SIGMA * mu, mu_lo = mu * (1.0 / K_SIGMA);
       auto upd = [&](const Bnd& q, Item& it, double ds, double snew) {
         double dvL, dvU; item_dv(q, it, ds, mu, dvL, dvU);
         it.vL += a_du * dvL; it.vU += a_du * dvU;
         item_recip(q, snew, it);
-        if (q.hasL) it.vL = fmax(fmin(it.vL, K_SIGMA * mu * it.iL), mu * it.iL / K_SIGMA);
-        if (q.hasU) it.vU = fmax(fmin(it.vU, K_SIGMA * mu * it.iU), mu * it.iU / K_SIGMA);
+        if (q.hasL) it.vL = fmax(fmin(it.vL, mu_hi * it.iL), mu_lo * it.iL);
+        if (q.hasU) it.vU = fmax(fmin(it.vU, mu_hi * it.iU), mu_lo * it.iU);
       };
       if (bu0_on) upd(qU0, iU0, dU[0], Ut[0]);
       if (bu1_on) upd(qU1, iU1, dU[1], Ut[1]);
@@ -1180,7 +1186,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         const double dv = mu * iO[j] - vO[j] - vO[j] * iO[j] * dsO[j];
         vO[j] += a_du * dv;
         iO[j] = wv::rcp(sOt[j] - qO.L);
-        vO[j] = fmax(fmin(vO[j], K_SIGMA * mu * iO[j]), mu * iO[j] / K_SIGMA);
+        vO[j] = fmax(fmin(vO[j], mu_hi * iO[j]), mu_lo * iO[j]);
         if (RESTO && rs) {
           eP[j] = pt[j]; eN[j] = nt[j];
           vP[j] += a_du * dvP[j]; vN[j] += a_du * dvN[j];
