@@ -351,7 +351,7 @@ bool is_gen(const mpcb_config& c) { return c.model == MPCB_MODEL_KIN && c.obs_mo
 
 size_t lds_bytes(const mpcb_config& c, int nz) {
   return (size_t)(c.model == MPCB_MODEL_DYN ? mpcbk::layout_dyn(c.N, false, mpcbk::obs_in_lds(mpcbk::obs_capacity_dyn(c.n_obs))).total
-                                             : mpcbk::layout_kin(c.N, nz, false, mpcbk::obs_in_lds(mpcbk::obs_capacity_kin(c.n_obs, is_gen(c)))).total) * sizeof(double);
+                                             : mpcbk::layout_kin(c.N, nz, false, mpcbk::obs_in_lds(mpcbk::obs_capacity_kin(c.n_obs, is_gen(c))), is_gen(c)).total) * sizeof(double);
 }
 
 // oldest recorded pair -> total_ms / last_ms / launches
@@ -433,7 +433,7 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in) {
     a.pass = 1;
     const bool dyn = h->cfg.model == MPCB_MODEL_DYN;
     const size_t lds2 = (size_t)(dyn ? mpcbk::layout_dyn(h->cfg.N, true, mpcbk::obs_in_lds(mpcbk::obs_capacity_dyn(n))).total
-                                     : mpcbk::layout_kin(h->cfg.N, h->nz, true, mpcbk::obs_in_lds(mpcbk::obs_capacity_kin(n, is_gen(h->cfg)))).total) * sizeof(double);
+                                     : mpcbk::layout_kin(h->cfg.N, h->nz, true, mpcbk::obs_in_lds(mpcbk::obs_capacity_kin(n, is_gen(h->cfg))), is_gen(h->cfg)).total) * sizeof(double);
     if (lds2 > 160 * 1024) return fail(h, MPCB_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds2);
     const bool gen = h->cfg.obs_mode == MPCB_OBS_DCBF && h->cfg.gamma < 1.0 - 1e-12 && n > 0;
     if (dyn) {

@@ -79,12 +79,10 @@ enum CostRow { CT_WQ = 0, CT_XR = 4, CT_WR = 8, CT_UR = 10, CT_QQ = 12, CT_RR = 
 
 // compact stage entries of the kinematic model, variable order of a stage: [x, y, phi, v, dprev, aprev, d, a]
 enum KinEnt {
-  E_ZERO = 0, E_ONE, E_T,
-  E_A02, E_A03, E_A12, E_A13, E_A23, E_B20,           // nontrivial entries of [A B]
-  E_D0, E_D1, E_D2, E_D3,                               // dynamics defect F_k - X_{k+1}
+  E_ZERO = 0, E_ONE,                                    // ([A B], the defect and the step length live in the fw rows only)
   E_G0, E_G1, E_G2, E_G3, E_G4, E_G5, E_G6, E_G7,       // condensed gradient
   E_HXX, E_HXY, E_HYY, E_HPP, E_HPV, E_HVV, E_HVD, E_HDD, E_HAA, E_H44, E_H55, E_H46, E_H57,
-  E_HXP, E_HXV, E_HYP, E_HYV,                           // only non-zero with general-gamma CBF rows (GEN kernels)
+  E_HXP, E_HXV, E_HYP, E_HYV,                           // only with general-gamma CBF rows: the GEN kernels' tables have these four rows more
   KIN_NENT
 };
 
@@ -92,13 +90,14 @@ enum KinEnt {
 //   Pst [N+1][PST]   P_k (6x6, row-major, slots 0..35), p_k (slots 36..41), a permanent 0.0 (slot 42: unit term of lanes
 //                    without one), pad slot 43 (p stores of non-affine lanes), pad slots 44..47 (P stores of lanes without a
 //                    P entry)
-//   fw  [N+1][FWS]   what the forward roll-out reads for stage k, as six records of FWR doubles, one per component of
-//                    [dX_{k+1}; dU_k]: coefficients of [dX_k; dU_{k-1}] (6), constant, coefficients of dU_k (2), one pad slot.
-//                    Records 0..3 are the rows of [A | d | B] (unit and zero entries written once per solve, a02 a03 a12 a13
-//                    a23 b20 d0..d3 and the stage's step length T_k per iteration), records 4, 5 the gain rows K and kff
-//                    (written by the sweep).  The pad slots take the K stores of lanes without a K entry.
+//   fw  [N+1][FWS]   the stage's [A | d | B], step length and gains as six records of FWR doubles, one per component of
+//                    [dX_{k+1}; dU_k]: coefficients of [dX_k; dU_{k-1}] (6), constant, coefficient of the stage's control (b20 on
+//                    dU_k[0] in record 2, T_k on dU_k[1] in record 3).  Records 0..3 are the rows of [A | d | B] (unit and zero
+//                    entries written once per solve, a02 a03 a12 a13 a23 b20 d0..d3 T_k per iteration), records 4, 5 the gain rows
+//                    K and kff (written by the sweep).  Read by the forward roll-out (lane i its record) AND by the sweep (each
+//                    lane its own slots of [A B | d]): a single copy.  Two pad slots take the K stores of lanes without a K entry.
 constexpr int PST = 48, PS_P = 36, PS_ZERO = 42, PS_PADP = 43, PS_PAD = 44;
-constexpr int FWR = 10, FWS = 62, FW_C0 = 6, FW_B0 = 7, FW_B1 = 8, FW_PAD = 9, WSZ = 136, W_ZERO = 64, W_STAGE = 72;
+constexpr int FWR = 8, FWS = 50, FW_C0 = 6, FW_BX = 7, FW_PAD = 48, FW_ZERO = 1, FW_ONE = 0, WSZ = 136, W_ZERO = 64, W_STAGE = 72;
 // constant block: uniform numbers of the instance that the node-parallel phases read from LDS (one ds_read, short live range)
 // instead of holding ~25 SGPR pairs through the whole solve
 constexpr int CS_WQ = 0, CS_WR = 4, CS_WDR = 6, CS_Q = 8, CS_R = 12, CS_DR = 14, CS_UL = 16, CS_XS = 18, CSZ = 24;
@@ -110,7 +109,7 @@ struct Layout {
 // 8-obstacle instantiations are far beyond the register file otherwise)
 MPCB_HD int obs_capacity_kin(int n, bool gen = false) { return n <= 0 ? (gen ? 1 : 0) : n == 1 ? 1 : n <= 3 ? 3 : (n <= 5 && !gen) ? 5 : 8; }   // (no GEN<5> instantiation)
 MPCB_HD int obs_in_lds(int capacity) { return capacity > 3 ? capacity : 0; }
-MPCB_HD Layout layout_kin(int N, int nz, bool resto = false, int nobl = 0) {
+MPCB_HD Layout layout_kin(int N, int nz, bool resto = false, int nobl = 0, bool gen = true) {
   Layout L;
   const int N1 = N + 1;
   L.ld = N1 | 1;
@@ -120,7 +119,7 @@ MPCB_HD Layout layout_kin(int N, int nz, bool resto = false, int nobl = 0) {
   L.W = o; o += WSZ;                 // W^T (8 columns x 6) + 16 pad slots + a permanent 0.0 (W_ZERO) + the staging block of the sweep's tail (64)
   L.cst = o; o += CSZ;
   L.filt = o; o += 2 * FILTER_MAX;
-  L.ent = o; o += KIN_NENT * L.ld;
+  L.ent = o; o += (gen ? KIN_NENT : KIN_NENT - 4) * L.ld;
   L.zbuf = L.Pst;                    // staging of z rows aliases the Riccati storage (used before / after the loop)
   (void)nz;
   L.ct = o; if (resto) o += CT_ROWS * 64;
@@ -217,7 +216,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   const int nz = a.nz, nobs = c.n_obs;
   if (RESTO && a.status[(size_t)b * a.st_stride] != MPCB_ST_NEEDS_RESTO) return;     // wave-uniform: this instance is done
   constexpr bool OBL = NOBS > 3;                  // obstacle constants in LDS ([4 * j + q][lane]) instead of registers
-  const Layout L = layout_kin(N, nz, RESTO, obs_in_lds(NOBS));
+  const Layout L = layout_kin(N, nz, RESTO, obs_in_lds(NOBS), GEN);
   const int ld = L.ld;
   double* ent = lds + L.ent;
   // step length of this lane's stage: cfg.T, or the stage's entry of the time grid (lanes past the last stage take its value)
@@ -561,22 +560,22 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
 
   // ----- per-lane constants of the Riccati sweep: lane = entry (i, j) of the 8x8 stage block -------------------
   const int ei = lane >> 3, ej = lane & 7;
-  auto slotAB = [&](int r, int col) -> int {   // entry [A B | aug](r, col), r < NA, col < NW
+  auto slotAB = [&](int r, int col) -> int {   // slot of entry [A B | aug](r, col), r < NA, col < NW, inside the stage's fw row
     if (r < NX) {
       if (col < NX) {
-        if (r == col) return E_ONE;
-        if (r == 0 && col == 2) return E_A02;
-        if (r == 0 && col == 3) return E_A03;
-        if (r == 1 && col == 2) return E_A12;
-        if (r == 1 && col == 3) return E_A13;
-        if (r == 2 && col == 3) return E_A23;
-        return E_ZERO;
+        if (r == col) return FW_ONE;
+        if (r == 0 && col == 2) return 2;
+        if (r == 0 && col == 3) return 3;
+        if (r == 1 && col == 2) return FWR + 2;
+        if (r == 1 && col == 3) return FWR + 3;
+        if (r == 2 && col == 3) return 2 * FWR + 3;
+        return FW_ZERO;
       }
-      if (r == 2 && col == 6) return E_B20;
-      if (r == 3 && col == 7) return E_T;
-      return E_ZERO;
+      if (r == 2 && col == 6) return 2 * FWR + FW_BX;
+      if (r == 3 && col == 7) return 3 * FWR + FW_BX;
+      return FW_ZERO;
     }
-    return (col == r + 2) ? E_ONE : E_ZERO;    // Uprev_{k+1} = U_k
+    return (col == r + 2) ? FW_ONE : FW_ZERO;    // Uprev_{k+1} = U_k
   };
   auto slotH = [&](int r, int col) -> int {
     int lo = r < col ? r : col, hi = r < col ? col : r;
@@ -613,8 +612,8 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   int sCW[NX], sCM[NX];
 #pragma unroll
   for (int r = 0; r < NX; ++r) {
-    sCW[r] = (aff ? E_D0 + r : slotAB(r, ej)) * ld;
-    sCM[r] = slotAB(r, ei) * ld;
+    sCW[r] = aff ? r * FWR + FW_C0 : slotAB(r, ej);      // (slots of the fw row, not of the entry table)
+    sCM[r] = slotAB(r, ei);
   }
   const int sHij = slotH(ei, ej) * ld, sGi = (E_G0 + ei) * ld;
   const int sStart = aff ? sGi : sHij;         // start value of the M accumulation: g_i in the affine lanes, H_ij elsewhere
@@ -629,25 +628,25 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   const int pOff = upper ? ei * NA + ej : PS_PAD + (lane & 1), pOffT = upper ? ej * NA + ei : PS_PAD + 2 + (lane & 1);
   const int psOff = (aff && ei < NA) ? PS_P + ei : PS_PADP;
   // gains: lanes (0,j) store K0j, lanes (1,j) store K1j (j < 6); lanes 62 / 63 store the feed-forward terms
-  const int kOff = (ej < NA && ei == 0) ? NX * FWR + ej : (ej < NA && ei == 1) ? (NX + 1) * FWR + ej : FW_PAD + FWR * (lane & 1);
-  const int kfOff = (lane == 62) ? NX * FWR + FW_C0 : (lane == 63) ? (NX + 1) * FWR + FW_C0 : 2 * FWR + FW_PAD + FWR * (lane & 1);
+  const int kOff = (ej < NA && ei == 0) ? NX * FWR + ej : (ej < NA && ei == 1) ? (NX + 1) * FWR + ej : FW_PAD + (lane & 1);
+  const int kfOff = (lane == 62) ? NX * FWR + FW_C0 : (lane == 63) ? (NX + 1) * FWR + FW_C0 : FW_PAD + (lane & 1);
   const bool kRow1 = (ei == 1), kfLane1 = (lane == 63);
 
   // constant rows of the entry table
-  if (isnode) { ent[E_ZERO * ld + k] = 0.0; ent[E_ONE * ld + k] = 1.0; ent[E_T * ld + k] = T; }
+  if (isnode) { ent[E_ZERO * ld + k] = 0.0; ent[E_ONE * ld + k] = 1.0; }
   // (Pst slot PS_ZERO = 0.0 is written after the z0 staging below has finished with the aliased region)
 
   double* Pst = lds + L.Pst; double* fw = lds + L.fw;
   double* Wl = (double*)__builtin_assume_aligned(lds + L.W, 16); double* filt = lds + L.filt;
   double* Sl = (double*)__builtin_assume_aligned(Wl + W_STAGE, 16);
   if (lane == 0) Wl[W_ZERO] = 0.0;
-  if (isnode) {            // unit and zero entries of the roll-out records (never written again)
+  if (isnode) {            // unit and zero entries of the records (never written again)
     double* fk = fw + k * FWS;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
 #pragma unroll
-      for (int r = 0; r < FWR - 1; ++r) {
-        const bool var = i >= NX ? r <= FW_C0 : (r == FW_C0 || (i == 0 && (r == 2 || r == 3)) || (i == 1 && (r == 2 || r == 3)) || (i == 2 && (r == 3 || r == FW_B0)) || (i == 3 && r == FW_B1));
+      for (int r = 0; r < FWR; ++r) {
+        const bool var = i >= NX ? r <= FW_C0 : (r == FW_C0 || (i == 0 && (r == 2 || r == 3)) || (i == 1 && (r == 2 || r == 3)) || (i == 2 && (r == 3 || r == FW_BX)) || (i == 3 && r == FW_BX));
         if (!var) fk[i * FWR + r] = (i < NX && r == i) ? 1.0 : 0.0;
       }
     }
@@ -1012,16 +1011,11 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           }
         }
         if (isnode) {
-          ent[E_A02 * ld + k] = hasu ? a02 : 0.0; ent[E_A03 * ld + k] = hasu ? a03 : 0.0;
-          ent[E_A12 * ld + k] = hasu ? a12 : 0.0; ent[E_A13 * ld + k] = hasu ? a13 : 0.0;
-          ent[E_A23 * ld + k] = hasu ? a23 : 0.0; ent[E_B20 * ld + k] = hasu ? b20 : 0.0;
-#pragma unroll
-          for (int i = 0; i < NX; ++i) ent[(E_D0 + i) * ld + k] = dfc[i];
 #pragma unroll
           for (int i = 0; i < NW; ++i) ent[(E_G0 + i) * ld + k] = g[i];
-          double* fk = fw + k * FWS;                     // the same numbers once more, as the roll-out's records
+          double* fk = fw + k * FWS;                     // [A | d | B] and T of the stage: the variable slots of records 0..3
           fk[2] = hasu ? a02 : 0.0; fk[3] = hasu ? a03 : 0.0; fk[FWR + 2] = hasu ? a12 : 0.0; fk[FWR + 3] = hasu ? a13 : 0.0;
-          fk[2 * FWR + 3] = hasu ? a23 : 0.0; fk[2 * FWR + FW_B0] = hasu ? b20 : 0.0; fk[3 * FWR + FW_B1] = T;
+          fk[2 * FWR + 3] = hasu ? a23 : 0.0; fk[2 * FWR + FW_BX] = hasu ? b20 : 0.0; fk[3 * FWR + FW_BX] = T;
 #pragma unroll
           for (int i = 0; i < NX; ++i) fk[i * FWR + FW_C0] = dfc[i];
           Pst[k * PST + PS_ZERO] = 0.0;
@@ -1056,7 +1050,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         struct StageEnt { double cw[NX], cm[NX], start, hmat; };
         auto load_ent = [&](int s, StageEnt& e) {
 #pragma unroll
-          for (int r = 0; r < NX; ++r) { e.cw[r] = ent[sCW[r] + s]; e.cm[r] = ent[sCM[r] + s]; }
+          for (int r = 0; r < NX; ++r) { e.cw[r] = fw[s * FWS + sCW[r]]; e.cm[r] = fw[s * FWS + sCM[r]]; }
           e.start = ent[sStart + s]; e.hmat = ent[sHij + s];
         };
         // gains of the previous stage, stored one stage late: the selects and the two DS stores then issue while this stage
@@ -1168,12 +1162,12 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         // so that the store needs no EXEC change
         double* hist = ent + (E_G0 + (lq < NA ? lq : NA + (lq & 1))) * ld + (lq < NX ? 1 : 0);
         if (lane < NX) hist[-1] = 0.0;                                   // dX_0 = 0 (X_0 is pinned)
-        struct FwRec { double c[NA], c0, b0, b1; };
+        struct FwRec { double c[NA], c0, bx; };
         auto load_fw = [&](int s, FwRec& f) {
-          const double* q = fw + s * FWS + li * FWR;      // one address, nine immediates
+          const double* q = fw + s * FWS + li * FWR;      // one address, four 16-byte reads
 #pragma unroll
           for (int r = 0; r < NA; ++r) f.c[r] = q[r];
-          f.c0 = q[FW_C0]; f.b0 = q[FW_B0]; f.b1 = q[FW_B1];
+          f.c0 = q[FW_C0]; f.bx = q[FW_BX];
         };
         double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;           // wave-uniform
         auto fstage = [&](int s, const FwRec& f, FwRec& nxt) {
@@ -1181,7 +1175,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           MPCB_SCHED_FENCE();
           const double t = fma(f.c[5], v5, fma(f.c[4], v4, fma(f.c[3], v3, fma(f.c[2], v2, fma(f.c[1], v1, fma(f.c[0], v0, f.c0))))));
           const double du0 = wv::bcast(t, NX), du1 = wv::bcast(t, NX + 1);
-          const double n = fma(f.b1, du1, fma(f.b0, du0, t));
+          const double n = fma(f.bx, lq == 3 ? du1 : du0, t);      // the control enters row 2 (b20 dU[0]) and row 3 (T dU[1])
           hist[s] = n;
           v0 = wv::bcast(n, 0); v1 = wv::bcast(n, 1); v2 = wv::bcast(n, 2); v3 = wv::bcast(n, 3); v4 = du0; v5 = du1;
         };
