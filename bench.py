@@ -150,7 +150,7 @@ def closed_loop_bench(args, bs, cfg, x0, xs, obs, workload, grp, local_rank):
     from mpc_motion_planning_amd import _abi
     from mpc_motion_planning_amd.solver import BatchSolver, dims
     sim_steps = 80                                            # sim_time 8 s / T_S 0.1 (main_cbf_kin_c_sim.py:68,87)
-    F = max(1, min(int(os.environ.get("MPCB_C5_LOOPS", "4")), args.inflight + 1))
+    F = max(1, min(int(os.environ.get("MPCB_C5_LOOPS", "6")), args.inflight + 1))
     H = [bs] + [BatchSolver(cfg, device=local_rank) for _ in range(F - 1)]
     parts = np.array_split(np.arange(len(x0)), F)
     for h_ in H:
@@ -240,7 +240,7 @@ def closed_loop_bench(args, bs, cfg, x0, xs, obs, workload, grp, local_rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="instances per GPU per step (default: the config's BASELINE batch)")
     ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
@@ -248,7 +248,7 @@ def main():
                          "obstacles B=32768; C4 dyn N=40 3 obstacles B=8192/GPU; C5 closed loop 80 steps (solves = scenes x steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-restoration", action="store_true", help="cfg.restoration = 0: a failed line search ends the solve (round-1 behaviour)")
-    ap.add_argument("--inflight", type=int, default=4,
+    ap.add_argument("--inflight", type=int, default=6,
                     help="solver handles (= HIP streams) used round-robin: step k+1 is launched while the tail of step k drains (a launch "
                          "ends with its slowest instance and leaves most SIMDs idle before that); 1 = strictly one launch at a time")
     ap.add_argument("--batches", type=int, default=5,
