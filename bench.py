@@ -51,8 +51,9 @@ def measured_traffic(workload):
     p = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         t = json.load(open(p))
-        if t.get("workload_key") == workload.split(":")[0]:
-            return float(t["bytes_per_launch"]), "offline: profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE of this command, committed)"
+        for e in (t if isinstance(t, list) else [t]):          # one entry per profiled workload
+            if e.get("workload_key") == workload.split(":")[0]:
+                return float(e["bytes_per_launch"]), "offline: profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE of this command, committed)"
     except (OSError, ValueError, KeyError):
         pass
     return None, None
