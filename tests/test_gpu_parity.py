@@ -458,7 +458,7 @@ def test_every_kernel_instantiation_full_outputs(gpu_solver_factory, oracle_mod,
     """Each compiled kernel variant (kin<0,1,3,5,8>, dyn<1,3,5,8>) with every output array against the oracle — catches
     variant-specific code-generation problems (one was found in dyn<3>: a spilled LDS address of the output staging)."""
     rng = np.random.default_rng(100 + n_obs)
-    B = 48
+    B = 96
     if model == 0:
         cfg = default_config(N=30, n_obs=n_obs); tol = TOL_Z
         x0, xs, ob1 = scenes.sample_c2(B, seed=40 + n_obs)
@@ -473,7 +473,10 @@ def test_every_kernel_instantiation_full_outputs(gpu_solver_factory, oracle_mod,
         obs = obs[:, :n_obs]
     g = gpu_solver_factory(cfg).solve_batch(x0, xs, obs if n_obs else None, multipliers=True)
     r = oracle_mod.solve(cfg, x0, xs, obs if n_obs else None)
-    both = agree(g, r, tol=tol, min_same_status=0.95)
+    # Measured agreement (tools/probe_variants.py, 256 instances per variant): >= 99.6 % equal statuses, >= 97 % equal iteration counts.
+    # The GPU-only wrong-code cases met so far showed as 78..95 % equal statuses and <= 92 % equal iteration counts.
+    both = agree(g, r, tol=tol, min_same_status=0.97)
+    assert (g["iters"][both] == r["iters"][both]).mean() >= 0.94
     sc_g = np.maximum(1.0, np.abs(r["lam_g"][both]).max(axis=1, keepdims=True))
     assert (np.abs(g["lam_g"][both] - r["lam_g"][both]) / sc_g).max() <= 1e-4
     sc_x = np.maximum(1.0, np.abs(r["lam_x"][both]).max(axis=1, keepdims=True))
@@ -500,7 +503,8 @@ def test_general_gamma_cbf_rows(gpu_solver_factory, oracle_mod, n_obs, gamma):
     cfg = default_config(N=30, n_obs=n_obs); cfg.obs_mode = _abi.OBS_DCBF; cfg.gamma = gamma
     x0, xs, _, traj = scenes.sample_c3(96, N=30, dt=0.1, seed=300 + n_obs, n_obs=n_obs)
     g = gpu_solver_factory(cfg).solve_batch(x0, xs, traj, multipliers=True); r = oracle_mod.solve(cfg, x0, xs, traj)
-    both = agree(g, r, min_same_status=0.95)
+    both = agree(g, r, min_same_status=0.97)
+    assert (g["iters"][both] == r["iters"][both]).mean() >= 0.94
     sc = np.maximum(1.0, np.abs(r["lam_g"][both]).max(axis=1, keepdims=True))
     assert (np.abs(g["lam_g"][both] - r["lam_g"][both]) / sc).max() <= 1e-4
     assert np.abs(g["obj"][both] / r["obj"][both] - 1).max() <= 1e-8
