@@ -73,7 +73,7 @@ constexpr int TRIG_K = 5;
 constexpr int RS_MAX_CALLS = 3, RS_MAX_ITERS = 40;
 // hand-over record of an instance that needs the restoration pass
 constexpr int WK_MU = 0, WK_THMAX = 1, WK_THMIN = 2, WK_ITERS = 3, WK_DW = 4, WK_SIZE = 8;
-// per-node cost table of the RESTO instantiations, [row][64] in LDS (lane = node): scaled weights osc*2*Qc, reference point,
+// per-node cost table of the RESTO instantiations, [row][N+2] in LDS (lane = node, lanes beyond the last node share the dummy column N+1): scaled weights osc*2*Qc, reference point,
 // osc*2*Rc, control reference, the unscaled weights Qc, Rc, and the rate-cost weights osc*2*DRc, DRc
 enum CostRow { CT_WQ = 0, CT_XR = 4, CT_WR = 8, CT_UR = 10, CT_QQ = 12, CT_RR = 16, CT_WDR = 18, CT_DRR = 20, CT_ROWS = 22 };
 
@@ -122,7 +122,7 @@ MPCB_HD Layout layout_kin(int N, int nz, bool resto = false, int nobl = 0, bool 
   L.ent = o; o += (gen ? KIN_NENT : KIN_NENT - 4) * L.ld;
   L.zbuf = L.Pst;                    // staging of z rows aliases the Riccati storage (used before / after the loop)
   (void)nz;
-  L.ct = o; if (resto) o += CT_ROWS * 64;
+  L.ct = o; if (resto) o += CT_ROWS * (N + 2);
   L.obl = o; o += 4 * nobl * 64;
   L.total = o;
   return L;
@@ -324,28 +324,29 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   // a per-node table (lane = node, every lane reads and writes only its own column), because the restoration phase replaces
   // the cost by the proximity term zeta/2 ||D_R (w - w_R)||^2 with per-node weights and reference (oracle: set_resto_cost).
   double* ct = lds + L.ct;
+  const int cts = N + 2, ctl = lane <= N ? lane : N + 1;     // row length of the cost table; lanes beyond the last node share a dummy column
   double osc = os;                       // scale of the running phase's objective: os, or 1 in the restoration phase
   bool rs = false;                       // restoration phase active
-  auto cWQ = [&](int i) { return RESTO ? ct[(CT_WQ + i) * 64 + lane] : cst[CS_WQ + i]; };
-  auto cXS = [&](int i) { return RESTO ? ct[(CT_XR + i) * 64 + lane] : cst[CS_XS + i]; };
-  auto cQQ = [&](int i) { return RESTO ? ct[(CT_QQ + i) * 64 + lane] : cst[CS_Q + i]; };
-  auto cWR = [&](int i) { return RESTO ? ct[(CT_WR + i) * 64 + lane] : cst[CS_WR + i]; };
-  auto cRR = [&](int i) { return RESTO ? ct[(CT_RR + i) * 64 + lane] : cst[CS_R + i]; };
-  auto cUR = [&](int i) { return RESTO ? ct[(CT_UR + i) * 64 + lane] : 0.0; };
-  auto cWDR = [&](int i) { return RESTO ? ct[(CT_WDR + i) * 64 + lane] : cst[CS_WDR + i]; };
-  auto cDRR = [&](int i) { return RESTO ? ct[(CT_DRR + i) * 64 + lane] : cst[CS_DR + i]; };
+  auto cWQ = [&](int i) { return RESTO ? ct[(CT_WQ + i) * cts + ctl] : cst[CS_WQ + i]; };
+  auto cXS = [&](int i) { return RESTO ? ct[(CT_XR + i) * cts + ctl] : cst[CS_XS + i]; };
+  auto cQQ = [&](int i) { return RESTO ? ct[(CT_QQ + i) * cts + ctl] : cst[CS_Q + i]; };
+  auto cWR = [&](int i) { return RESTO ? ct[(CT_WR + i) * cts + ctl] : cst[CS_WR + i]; };
+  auto cRR = [&](int i) { return RESTO ? ct[(CT_RR + i) * cts + ctl] : cst[CS_R + i]; };
+  auto cUR = [&](int i) { return RESTO ? ct[(CT_UR + i) * cts + ctl] : 0.0; };
+  auto cWDR = [&](int i) { return RESTO ? ct[(CT_WDR + i) * cts + ctl] : cst[CS_WDR + i]; };
+  auto cDRR = [&](int i) { return RESTO ? ct[(CT_DRR + i) * cts + ctl] : cst[CS_DR + i]; };
   auto write_main_cost = [&]() {         // kin.py:168-205: Q on nodes 0..N-1 (no terminal cost), R, DR; set-point xs, U reference 0
     if (RESTO) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
-        ct[(CT_WQ + i) * 64 + lane] = hasu ? os * 2 * c.Q[i] : 0.0; ct[(CT_QQ + i) * 64 + lane] = hasu ? c.Q[i] : 0.0;
-        ct[(CT_XR + i) * 64 + lane] = xs[i];
+        ct[(CT_WQ + i) * cts + ctl] = hasu ? os * 2 * c.Q[i] : 0.0; ct[(CT_QQ + i) * cts + ctl] = hasu ? c.Q[i] : 0.0;
+        ct[(CT_XR + i) * cts + ctl] = xs[i];
       }
 #pragma unroll
       for (int i = 0; i < NU; ++i) {
-        ct[(CT_WR + i) * 64 + lane] = hasu ? os * 2 * c.R[i] : 0.0; ct[(CT_RR + i) * 64 + lane] = hasu ? c.R[i] : 0.0;
-        ct[(CT_UR + i) * 64 + lane] = 0.0;
-        ct[(CT_WDR + i) * 64 + lane] = os * 2 * c.DR[i]; ct[(CT_DRR + i) * 64 + lane] = c.DR[i];
+        ct[(CT_WR + i) * cts + ctl] = hasu ? os * 2 * c.R[i] : 0.0; ct[(CT_RR + i) * cts + ctl] = hasu ? c.R[i] : 0.0;
+        ct[(CT_UR + i) * cts + ctl] = 0.0;
+        ct[(CT_WDR + i) * cts + ctl] = os * 2 * c.DR[i]; ct[(CT_DRR + i) * cts + ctl] = c.DR[i];
       }
     }
   };
@@ -354,18 +355,18 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     if (RESTO) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
-        if (fresh) ct[(CT_XR + i) * 64 + lane] = Xc[i];
-        const double d = 1.0 / fmax(1.0, fabs(ct[(CT_XR + i) * 64 + lane]));
+        if (fresh) ct[(CT_XR + i) * cts + ctl] = Xc[i];
+        const double d = 1.0 / fmax(1.0, fabs(ct[(CT_XR + i) * cts + ctl]));
         const double q = xnode ? 0.5 * zeta * d * d : 0.0;
-        ct[(CT_QQ + i) * 64 + lane] = q; ct[(CT_WQ + i) * 64 + lane] = 2 * q;
+        ct[(CT_QQ + i) * cts + ctl] = q; ct[(CT_WQ + i) * cts + ctl] = 2 * q;
       }
 #pragma unroll
       for (int i = 0; i < NU; ++i) {
-        if (fresh) ct[(CT_UR + i) * 64 + lane] = Uc[i];
-        const double d = 1.0 / fmax(1.0, fabs(ct[(CT_UR + i) * 64 + lane]));
+        if (fresh) ct[(CT_UR + i) * cts + ctl] = Uc[i];
+        const double d = 1.0 / fmax(1.0, fabs(ct[(CT_UR + i) * cts + ctl]));
         const double q = hasu ? 0.5 * zeta * d * d : 0.0;
-        ct[(CT_RR + i) * 64 + lane] = q; ct[(CT_WR + i) * 64 + lane] = 2 * q;
-        ct[(CT_WDR + i) * 64 + lane] = 0.0; ct[(CT_DRR + i) * 64 + lane] = 0.0;
+        ct[(CT_RR + i) * cts + ctl] = q; ct[(CT_WR + i) * cts + ctl] = 2 * q;
+        ct[(CT_WDR + i) * cts + ctl] = 0.0; ct[(CT_DRR + i) * cts + ctl] = 0.0;
       }
     }
   };

@@ -34,7 +34,7 @@ enum DynEnt {
 constexpr int DPST = 66 /* P_k 8x8 + 2 pad slots for the stores of the lanes below the diagonal */, DPSS = 10, DFWS = 46, DFW_KFF = 16, DFW_A = 18, DFW_B = 32, DFW_D = 34, DFW_PAD = 40, DFW_ONE = 42, DFW_ZERO = 43, DFW_T = 44, DWSZ = 64, DWU = 16 + 16;
 // constant block (as in the kin kernel): cost weights, reference state and last control, read from LDS by the node-parallel phases
 constexpr int DCS_WQ = 0, DCS_WR = 6, DCS_WDR = 8, DCS_Q = 10, DCS_R = 16, DCS_DR = 18, DCS_UL = 20, DCS_XS = 22, DCSZ = 28;
-// per-node cost table of the RESTO instantiation, [row][64] (see CostRow in mpcb_kernel.h)
+// per-node cost table of the RESTO instantiation, [row][N+2] (see CostRow in mpcb_kernel.h)
 enum DynCostRow { DCT_WQ = 0, DCT_XR = 6, DCT_WR = 12, DCT_UR = 14, DCT_QQ = 16, DCT_RR = 22, DCT_WDR = 24, DCT_DRR = 26, DCT_ROWS = 28 };
 struct LayoutDyn { int ld, ent, Pst, pst, fw, W, Wu, cst, filt, zbuf, ct, obl, total; };
 MPCB_HD int obs_capacity_dyn(int n) { return n <= 1 ? 1 : n <= 3 ? 3 : n <= 5 ? 5 : 8; }
@@ -52,7 +52,7 @@ MPCB_HD LayoutDyn layout_dyn(int N, bool resto = false, int nobl = 0) {
   L.filt = o; o += 2 * FILTER_MAX;
   L.ent = o; o += DYN_NENT * L.ld;
   L.zbuf = L.Pst;
-  L.ct = o; if (resto) o += DCT_ROWS * 64;
+  L.ct = o; if (resto) o += DCT_ROWS * (N + 2);
   L.obl = o; o += 4 * nobl * 64;
   L.total = o;
   return L;
@@ -237,28 +237,29 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   wv::sync();
   // objective of the running phase: uniform constants (first pass) or the per-node table of the RESTO instantiation
   double* ct = lds + L.ct;
+  const int cts = N + 2, ctl = lane <= N ? lane : N + 1;     // row length of the cost table; lanes beyond the last node share a dummy column
   double osc = os;
   bool rs = false;
-  auto cWQ = [&](int i) { return RESTO ? ct[(DCT_WQ + i) * 64 + lane] : cst[DCS_WQ + i]; };
-  auto cXS = [&](int i) { return RESTO ? ct[(DCT_XR + i) * 64 + lane] : cst[DCS_XS + i]; };
-  auto cQQ = [&](int i) { return RESTO ? ct[(DCT_QQ + i) * 64 + lane] : cst[DCS_Q + i]; };
-  auto cWR = [&](int i) { return RESTO ? ct[(DCT_WR + i) * 64 + lane] : cst[DCS_WR + i]; };
-  auto cRR = [&](int i) { return RESTO ? ct[(DCT_RR + i) * 64 + lane] : cst[DCS_R + i]; };
-  auto cUR = [&](int i) { return RESTO ? ct[(DCT_UR + i) * 64 + lane] : 0.0; };
-  auto cWDR = [&](int i) { return RESTO ? ct[(DCT_WDR + i) * 64 + lane] : cst[DCS_WDR + i]; };
-  auto cDRR = [&](int i) { return RESTO ? ct[(DCT_DRR + i) * 64 + lane] : cst[DCS_DR + i]; };
+  auto cWQ = [&](int i) { return RESTO ? ct[(DCT_WQ + i) * cts + ctl] : cst[DCS_WQ + i]; };
+  auto cXS = [&](int i) { return RESTO ? ct[(DCT_XR + i) * cts + ctl] : cst[DCS_XS + i]; };
+  auto cQQ = [&](int i) { return RESTO ? ct[(DCT_QQ + i) * cts + ctl] : cst[DCS_Q + i]; };
+  auto cWR = [&](int i) { return RESTO ? ct[(DCT_WR + i) * cts + ctl] : cst[DCS_WR + i]; };
+  auto cRR = [&](int i) { return RESTO ? ct[(DCT_RR + i) * cts + ctl] : cst[DCS_R + i]; };
+  auto cUR = [&](int i) { return RESTO ? ct[(DCT_UR + i) * cts + ctl] : 0.0; };
+  auto cWDR = [&](int i) { return RESTO ? ct[(DCT_WDR + i) * cts + ctl] : cst[DCS_WDR + i]; };
+  auto cDRR = [&](int i) { return RESTO ? ct[(DCT_DRR + i) * cts + ctl] : cst[DCS_DR + i]; };
   auto write_main_cost = [&]() {         // dyn.py:189-225
     if (RESTO) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
-        ct[(DCT_WQ + i) * 64 + lane] = hasu ? os * 2 * c.Q[i] : 0.0; ct[(DCT_QQ + i) * 64 + lane] = hasu ? c.Q[i] : 0.0;
-        ct[(DCT_XR + i) * 64 + lane] = xs[i];
+        ct[(DCT_WQ + i) * cts + ctl] = hasu ? os * 2 * c.Q[i] : 0.0; ct[(DCT_QQ + i) * cts + ctl] = hasu ? c.Q[i] : 0.0;
+        ct[(DCT_XR + i) * cts + ctl] = xs[i];
       }
 #pragma unroll
       for (int i = 0; i < NU; ++i) {
-        ct[(DCT_WR + i) * 64 + lane] = hasu ? os * 2 * c.R[i] : 0.0; ct[(DCT_RR + i) * 64 + lane] = hasu ? c.R[i] : 0.0;
-        ct[(DCT_UR + i) * 64 + lane] = 0.0;
-        ct[(DCT_WDR + i) * 64 + lane] = os * 2 * c.DR[i]; ct[(DCT_DRR + i) * 64 + lane] = c.DR[i];
+        ct[(DCT_WR + i) * cts + ctl] = hasu ? os * 2 * c.R[i] : 0.0; ct[(DCT_RR + i) * cts + ctl] = hasu ? c.R[i] : 0.0;
+        ct[(DCT_UR + i) * cts + ctl] = 0.0;
+        ct[(DCT_WDR + i) * cts + ctl] = os * 2 * c.DR[i]; ct[(DCT_DRR + i) * cts + ctl] = c.DR[i];
       }
     }
   };
@@ -266,18 +267,18 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
     if (RESTO) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
-        if (fresh) ct[(DCT_XR + i) * 64 + lane] = Xc[i];
-        const double d = 1.0 / fmax(1.0, fabs(ct[(DCT_XR + i) * 64 + lane]));
+        if (fresh) ct[(DCT_XR + i) * cts + ctl] = Xc[i];
+        const double d = 1.0 / fmax(1.0, fabs(ct[(DCT_XR + i) * cts + ctl]));
         const double q = xnode ? 0.5 * zeta * d * d : 0.0;
-        ct[(DCT_QQ + i) * 64 + lane] = q; ct[(DCT_WQ + i) * 64 + lane] = 2 * q;
+        ct[(DCT_QQ + i) * cts + ctl] = q; ct[(DCT_WQ + i) * cts + ctl] = 2 * q;
       }
 #pragma unroll
       for (int i = 0; i < NU; ++i) {
-        if (fresh) ct[(DCT_UR + i) * 64 + lane] = Uc[i];
-        const double d = 1.0 / fmax(1.0, fabs(ct[(DCT_UR + i) * 64 + lane]));
+        if (fresh) ct[(DCT_UR + i) * cts + ctl] = Uc[i];
+        const double d = 1.0 / fmax(1.0, fabs(ct[(DCT_UR + i) * cts + ctl]));
         const double q = hasu ? 0.5 * zeta * d * d : 0.0;
-        ct[(DCT_RR + i) * 64 + lane] = q; ct[(DCT_WR + i) * 64 + lane] = 2 * q;
-        ct[(DCT_WDR + i) * 64 + lane] = 0.0; ct[(DCT_DRR + i) * 64 + lane] = 0.0;
+        ct[(DCT_RR + i) * cts + ctl] = q; ct[(DCT_WR + i) * cts + ctl] = 2 * q;
+        ct[(DCT_WDR + i) * cts + ctl] = 0.0; ct[(DCT_DRR + i) * cts + ctl] = 0.0;
       }
     }
   };
