@@ -53,7 +53,7 @@ MPCB_HD LayoutDyn layout_dyn(int N, bool resto = false, int nobl = 0) {
   L.ent = o; o += DYN_NENT * L.ld;
   L.zbuf = L.Pst;
   L.ct = o; if (resto) o += DCT_ROWS * (N + 2);
-  L.obl = o; o += 4 * nobl * 64;
+  L.obl = o; o += 4 * nobl * (N + 2);
   L.total = o;
   return L;
 }
@@ -162,7 +162,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   double ox_[OBL ? 1 : NOB], oy_[OBL ? 1 : NOB], ix2_[OBL ? 1 : NOB], iy2_[OBL ? 1 : NOB];
   double* obl = lds + L.obl;
   auto OC = [&](int j, int q) -> double& {
-    if constexpr (OBL) return obl[(4 * j + q) * 64 + lane];
+    if constexpr (OBL) return obl[(4 * j + q) * (N + 2) + (lane <= N ? lane : N + 1)];   // rows of N+2: lanes beyond the last node share a dummy column
     else return q == 0 ? ox_[j] : q == 1 ? oy_[j] : q == 2 ? ix2_[j] : iy2_[j];
   };
 #define ox(j) OC(j, 0)
