@@ -96,7 +96,7 @@ enum KinEnt {
 //                    entries written once per solve, a02 a03 a12 a13 a23 b20 d0..d3 T_k per iteration), records 4, 5 the gain rows
 //                    K and kff (written by the sweep).  Read by the forward roll-out (lane i its record) AND by the sweep (each
 //                    lane its own slots of [A B | d]): a single copy.  Two pad slots take the K stores of lanes without a K entry.
-constexpr int PST = 48, PS_P = 36, PS_ZERO = 42, PS_PADP = 43, PS_PAD = 44;
+constexpr int PST = 50, PS_P = 36, PS_ZERO = 42, PS_PADP = 43, PS_PAD = 44;
 constexpr int FWR = 8, FWS = 50, FW_C0 = 6, FW_BX = 7, FW_PAD = 48, FW_ZERO = 1, FW_ONE = 0, WSZ = 136, W_ZERO = 64, W_STAGE = 72;
 // constant block: uniform numbers of the instance that the node-parallel phases read from LDS (one ds_read, short live range)
 // instead of holding ~25 SGPR pairs through the whole solve
