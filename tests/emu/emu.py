@@ -47,6 +47,12 @@ def solve(cfg, x0, xs, obs=None, z0=None, trace_instance=-1, tgrid=None):
     return dict(z=z, obj=obj, status=st, iters=it, kkt=kkt, lam_g=lam_g, lam_x=lam_x, trace=trace)
 
 
+def lds_bytes(cfg, restoration_pass=False):
+    """LDS bytes of one instance as the kernels lay it out (layout_kin / layout_dyn of the kernel headers)."""
+    f = lib().mpcb_emu_lds_bytes; f.restype = C.c_int64
+    return int(f(C.byref(cfg), C.c_int32(1 if restoration_pass else 0)))
+
+
 def dyn_model(cfg, X, U, lam):
     X = np.ascontiguousarray(X, np.float64); U = np.ascontiguousarray(U, np.float64); lam = np.ascontiguousarray(lam, np.float64)
     F = np.zeros(6); jac = np.zeros(16); hess = np.zeros(13)

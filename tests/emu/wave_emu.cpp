@@ -76,6 +76,16 @@ extern "C" int mpcb_emu_solve(const mpcb_config* cfg, int32_t B, const double* x
 }
 
 // closed-form dyn model derivatives of the kernel source (host-compiled) for comparison with the oracle's AD
+// LDS bytes of one instance (= one workgroup) as the kernels lay it out: `pass` 0 first pass, 1 restoration pass; as mpcb_api.hip computes it
+extern "C" int64_t mpcb_emu_lds_bytes(const mpcb_config* cfg, int32_t pass) {
+  using namespace mpcbk;
+  const int n = cfg->n_obs;
+  if (cfg->model == MPCB_MODEL_DYN) return (int64_t)layout_dyn(cfg->N, pass == 1, obs_in_lds(obs_capacity_dyn(n))).total * 8;
+  const bool gen = cfg->obs_mode == MPCB_OBS_DCBF && cfg->gamma < 1.0 - 1e-12 && n > 0;
+  const int nz = 2 * cfg->N + 4 * (cfg->N + 1);
+  return (int64_t)layout_kin(cfg->N, nz, pass == 1, obs_in_lds(obs_capacity_kin(n, gen)), gen).total * 8;
+}
+
 extern "C" int mpcb_emu_dyn_model(const mpcb_config* cfg, const double* X, const double* U, const double* lam, double* F, double* jac16,
                                   double* hess13) {
   using namespace mpcbk;

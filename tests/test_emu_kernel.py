@@ -116,3 +116,22 @@ def test_emulated_kernels_with_a_time_grid():
     assert (np.abs(np.diff(U[:, 0])) - 1e-8).max() <= (5 * np.pi / 180 * tg[:-1]).max() and ((np.abs(np.diff(U[:, 0])) - 2e-8) / tg[:-1]).max() <= 5 * np.pi / 180
     u = oracle.solve(c, x0, xs, obs); g = oracle.solve(c, x0, xs, obs, tgrid=np.full(30, 0.1))
     assert np.array_equal(u["z"], g["z"])                              # a grid of T_S everywhere is the fixed grid, bit for bit
+
+
+def test_lds_budget_of_the_benchmark_instances():
+    """The kernels run one wave per SIMD (register-bound: four workgroups per CU), so an instance must stay within 160 KB / 4 of LDS
+    where it can, and within 160 KB / 3 where it cannot: a table that grows past these lines costs a quarter or a third of the
+    throughput without failing any parity test (it happened in round 2 to N = 50 with a first version of the roll-out records)."""
+    CU = 160 * 1024
+    kin30 = oracle.default_config(N=30, n_obs=1)
+    assert emu.lds_bytes(kin30) <= CU // 4 and emu.lds_bytes(kin30, True) <= CU // 4             # C2: both passes four per CU
+    kin30_3 = oracle.default_config(N=30, n_obs=3)
+    assert emu.lds_bytes(kin30_3) <= CU // 4 and emu.lds_bytes(kin30_3, True) <= CU // 4         # C3 / C5
+    kin50 = oracle.default_config(N=50, n_obs=1)
+    assert emu.lds_bytes(kin50) <= CU // 3                                                        # the shipped YAML (N_p = 50): three per CU
+    dyn40 = oracle.default_config(model=_abi.MODEL_DYN, N=40, n_obs=3)
+    assert emu.lds_bytes(dyn40) <= CU // 3                                                        # C4: three per CU (two in round 1)
+    kin63_8 = oracle.default_config(N=63, n_obs=8)
+    assert emu.lds_bytes(kin63_8, True) <= CU                                                     # the largest instance still fits one CU
+    dyn63_8 = oracle.default_config(model=_abi.MODEL_DYN, N=63, n_obs=8)
+    assert emu.lds_bytes(dyn63_8, True) <= CU
