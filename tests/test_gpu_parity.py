@@ -742,3 +742,18 @@ def test_independent_kkt_certificate_on_256_solved_instances(gpu_solver_factory,
         for k in worst:
             worst[k] = max(worst[k], float(c[k] / (c["lam_scale"] if k == "stationarity" else 1.0)))
     print(conf, "worst over 256:", worst)
+
+
+def test_independent_sqp_solver_reaches_the_same_trajectories(gpu_solver_factory):
+    """The HIP path against an off-the-shelf NLP solver nobody here wrote (SciPy SLSQP on the NLP of oracle/kkt_check.py, from the
+    solvers' cold start; tests/test_independent_solver.py does the same for the oracle): kinematic C2 / C1 / C3 instances and a
+    dynamic-bicycle instance in the reference's row form, trajectory L-inf within north_star's 1e-4 (measured 2e-6 .. 4e-5)."""
+    from tests.test_independent_solver import cases
+    from oracle import scipy_crosscheck as sc
+    for name, cfg, x0, xs, obs, nlp, rhs0, tol in cases():
+        g = gpu_solver_factory(cfg).solve_batch(x0[None], xs[None], None if obs is None else obs[None])
+        assert g["status"][0] == 0, name
+        z, f, s = sc.solve_slsqp(nlp, sc.cold_start(nlp, cfg.T, rhs0))
+        err = np.abs(z - g["z"][0]).max()
+        assert err <= tol, "%s: L-inf %.2e" % (name, err)
+        assert abs(f / g["obj"][0] - 1) <= 1e-7, name
