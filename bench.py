@@ -44,32 +44,53 @@ PARITY_NOTE = ("parity UNPINNED vs the reference's CasADi+IPOPT (not installed h
                "independent KKT certificate (oracle/kkt_check.py)")
 
 
-def measured_traffic(workload):
-    """HBM bytes per launch of this workload from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate passes, KiB units,
-    2x correction on FETCH_SIZE as MI355X_MICROARCH.md prescribes), recorded by tools/profile_round.sh in profiles/traffic.json.
-    A process cannot collect PMC counters on itself, so this is the committed OFFLINE measurement of the same command; None if absent."""
+def measured_counters(workload):
+    """Counters of this workload from the rocprofv3 PMC passes of tools/profile_round.sh (separate passes, never mixed with tracing),
+    kept in profiles/traffic.json: HBM bytes per solve launch (FETCH_SIZE / WRITE_SIZE, KiB units, 2x correction on FETCH_SIZE as
+    MI355X_MICROARCH.md prescribes) and FP64 operations per solve launch (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64: wave instructions
+    x 64 lanes, FMA counted twice).  A process cannot collect PMC counters on itself, so this is the committed OFFLINE measurement
+    of the same command; the entry of the latest round wins.  {} if absent."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         t = json.load(open(p))
-        for e in (t if isinstance(t, list) else [t]):          # one entry per profiled workload
-            if e.get("workload_key") == workload.split(":")[0]:
-                return float(e["bytes_per_launch"]), "offline: profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE of this command, committed)"
+        hits = [e for e in (t if isinstance(t, list) else [t]) if e.get("workload_key") == workload.split(":")[0]]
+        if hits:
+            e = hits[-1]
+            return {"bytes_per_launch": e.get("bytes_per_launch"), "fp64_flop_per_launch": e.get("fp64_flop_per_launch"),
+                    "valu_busy": e.get("valu_busy"), "wait_any": e.get("wait_any"), "round": e.get("round"),
+                    "source": "offline: profiles/traffic.json (rocprofv3 --pmc passes of this command at --inflight 1, committed)"}
     except (OSError, ValueError, KeyError):
         pass
-    return None, None
+    return {}
 
 
-def algorithmic_bytes_per_solve(nx, nz, n_obs_values):
-    # SURVEY.md §8(d): 8*(2*nx + nz_in + obs_in + nz_out) + 16   (status i32 + iters i32 + obj f64)
-    return 8 * (2 * nx + nz + n_obs_values + nz) + 16
+def parity_evidence():
+    """The numbers of the independent-evidence tests of the GPU suite (tests/test_parity_evidence.py writes them on the GPU box,
+    the committed copy is profiles/parity_evidence.json): same-basin fractions against SciPy SLSQP, the IPOPT-default-start batches,
+    the audit of the MPCB_ST_INFEASIBLE verdicts.  None if the file is absent."""
+    for p in (os.path.join(ROOT, "gpurun_out", "parity_evidence.json"), os.path.join(ROOT, "profiles", "parity_evidence.json")):
+        try:
+            return json.load(open(p))
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def algorithmic_bytes_per_solve(nx, nz, n_obs_values, with_z0=True):
+    # SURVEY.md §8(d): 8*(2*nx + nz_in + obs_in + nz_out) + 16   (status i32 + iters i32 + obj f64).  Without a start vector
+    # (z0 = NULL: the cold start of main_cbf_kin_c_sim.py:47-50) the nz_in term is not compulsory: nothing is read.
+    return 8 * (2 * nx + (nz if with_z0 else 0) + n_obs_values + nz) + 16
 
 
 def host_cores():
+    """Every core this process may run on (the CPU leg uses all host cores); MPCB_CPU_THREADS overrides."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    return max(1, min(cores, int(os.environ.get("MPCB_CPU_THREADS", "16"))))   # the 1-GPU box's CPU share is 16 cores
+    if os.environ.get("MPCB_CPU_THREADS"):
+        cores = min(cores, int(os.environ["MPCB_CPU_THREADS"]))
+    return max(1, cores)
 
 
 def cpu_baseline(cfg, x0, xs, obs, min_seconds=1.5):
@@ -77,6 +98,7 @@ def cpu_baseline(cfg, x0, xs, obs, min_seconds=1.5):
     host cores on a bounded sample of the same workload.  Reported next to the GPU number; CasADi+IPOPT cannot be
     timed (not installed here nor on the GPU box, no network: SURVEY.md §0 F2)."""
     from oracle import oracle
+    native = oracle.use_native_build()
     cores = host_cores()
     n = min(len(x0), 2048)
     oracle.solve(cfg, x0[:4 * cores], xs[:4 * cores], obs[:4 * cores], threads=cores, want_multipliers=False)   # untimed: starts the OpenMP team, first-touch of the per-thread arenas
@@ -92,6 +114,8 @@ def cpu_baseline(cfg, x0, xs, obs, min_seconds=1.5):
     oracle.solve(cfg, x0[:m], xs[:m], obs[:m], threads=1, want_multipliers=False)
     lat_ms = 1e3 * (time.perf_counter() - t1) / m
     return {"value": solved / dt, "unit": "solves/s", "cores": cores, "kind": "port", "single_thread_ms_per_instance": lat_ms,
+            "build": ("g++ %s -fopenmp, compiled on this host" % native) if native else "g++ -O2 -fopenmp (portable build; no compiler on this host)",
+            "threads": "every core of the process's affinity mask (%d)" % cores,
             "sample": "%d x first %d instances of the step's batch, OpenMP over instances, %.1f s wall (%.0f core-s); latency: %d instances on one thread" % (reps, n, dt, dt * cores, m),
             "note": "own FP64 C++ restatement of the NLP + IPOPT-style solver; CasADi+IPOPT baseline unavailable (casadi not installed)"}
 
@@ -101,6 +125,7 @@ def cpu_baseline_closed_loop(cfg, x0, xs, obs, sim_steps, min_seconds=8.0):
     re-prediction: main_cbf_kin_c_sim_pre.py:86-126) on a bounded sample of the scenes, OpenMP over scenes inside every step."""
     from oracle import oracle
     from mpc_motion_planning_amd import scenes
+    native = oracle.use_native_build()
     cores = host_cores()
     n = min(len(x0), 768); N = cfg.N
     xc = x0[:n].copy(); oc = obs[:n].copy(); z0 = np.zeros((n, 2 * N + 4 * (N + 1)))
@@ -118,6 +143,7 @@ def cpu_baseline_closed_loop(cfg, x0, xs, obs, sim_steps, min_seconds=8.0):
             break
     dt = time.perf_counter() - t0
     return {"value": solved / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+            "build": ("g++ %s -fopenmp, compiled on this host" % native) if native else "g++ -O2 -fopenmp (portable build)",
             "sample": "%d scenes x %d of %d closed-loop steps, %.1f s wall (%.0f core-s)" % (n, done, sim_steps, dt, dt * cores),
             "note": "own FP64 C++ restatement (oracle) driving the same loop; CasADi+IPOPT baseline unavailable (casadi not installed)"}
 
@@ -250,8 +276,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-restoration", action="store_true", help="cfg.restoration = 0: a failed line search ends the solve (round-1 behaviour)")
     ap.add_argument("--inflight", type=int, default=6,
-                    help="solver handles (= HIP streams) used round-robin: step k+1 is launched while the tail of step k drains (a launch "
+                    help="launch lanes of the solver handle (mpcb_set_inflight): a batch is cut into that many chunks, chunk c of step k+1 "
+                         "starts when chunk c of step k has finished, while the slowest instances of the other chunks still run (a launch "
                          "ends with its slowest instance and leaves most SIMDs idle before that); 1 = strictly one launch at a time")
+    ap.add_argument("--handles", type=int, default=1, help="independent solver handles used round-robin (rounds 1-2 overlapped launches this way)")
     ap.add_argument("--batches", type=int, default=5,
                     help="distinct synthetic batches resident in HBM, used round-robin by the steps (the launch time of a 4096-instance "
                          "batch moves +-15 %% with where its slowest instances fall in the dispatch order; one batch would report one draw)")
@@ -307,17 +335,24 @@ def main():
     grp = Group(cfg, rank, world, local_rank, os.environ.get("MPCB_BENCH_FORCE_DIST") == "1")
     if conf == "C5":
         return closed_loop_bench(args, bs, cfg, x0, xs, obs, workload, grp, local_rank)
-    D = []                                                  # per batch: inputs and the status / iteration outputs, all resident in HBM
-    for (a0, a1, a2) in sets:
-        D.append(dict(x0=bs.device_array((B, nx)).upload(a0), xs=bs.device_array((B, nx)).upload(a1), obs=bs.device_array(a2.shape).upload(a2),
-                      st=bs.device_array((B,), np.int32), it=bs.device_array((B,), np.int32)))
-    d_x0 = D[0]["x0"]
-    cyc = [0]                                               # step counter: step k solves batch k mod NB on handle k mod F
+    # One solver handle with `--inflight` launch lanes (mpcb_set_inflight): consecutive asynchronous solves of ONE handle go to its
+    # lanes in turn and overlap inside the library.  --handles H > 1 adds independent handles (how rounds 1-2 overlapped launches).
     F = max(1, args.inflight)
-    H = [bs] + [BatchSolver(cfg, device=local_rank) for _ in range(F - 1)]     # one handle = one stream (include/mpcbatch.h)
-    d_obj = [bs.device_array((B,)) for _ in range(F)]; d_kkt = [bs.device_array((B, 4)) for _ in range(F)]
-    z_bufs = [bs.device_array((B, nz)) for _ in range(F)]
+    bs.set_inflight(F)
+    H = [bs] + [BatchSolver(cfg, device=local_rank, inflight=F) for _ in range(max(1, args.handles) - 1)]
+    HN = len(H)
+    R = F                                                   # ring of output-buffer sets per handle: solves closer than F apart may run concurrently
+    if HN * R > 16:
+        raise SystemExit("--handles x --inflight must be <= 16 (event slots of the gather ring)")
+    D = []                                                  # per batch: the inputs, resident in HBM
+    for (a0, a1, a2) in sets:
+        D.append(dict(x0=bs.device_array((B, nx)).upload(a0), xs=bs.device_array((B, nx)).upload(a1), obs=bs.device_array(a2.shape).upload(a2)))
+    d_x0 = D[0]["x0"]
+    cyc = [0]                                               # step counter: step k solves batch k mod NB on handle k mod HN, output set (k div HN) mod R
+    OUT = [[dict(z=bs.device_array((B, nz)), obj=bs.device_array((B,)), kkt=bs.device_array((B, 4)), st=bs.device_array((B,), np.int32),
+                 it=bs.device_array((B,), np.int32)) for _ in range(R)] for _ in range(HN)]
     z_all = grp.h.device_array((world * B, nz)) if grp.active else None
+    last = {}                                               # batch -> the output set its latest solve wrote
 
     d_z0 = None
     if args.warm:
@@ -336,15 +371,18 @@ def main():
 
     def step(gather=True):
         k = cyc[0]; cyc[0] += 1
-        d = D[k % NB]; hq = k % F
+        d = D[k % NB]; hq = k % HN; sl = (k // HN) % R; mark = hq * R + sl
+        o = OUT[hq][sl]; last[k % NB] = o; last["z"] = o["z"]
         if grp.active and gather:
-            H[hq].wait_for(grp.h)                       # the gather that last read this handle's z buffer must be done
-        H[hq].solve_device(B, d["x0"], d["xs"], d["obs"], obs_kind, d_z0, z_bufs[hq], d_obj[hq], d["st"], d["it"], d_kkt[hq])
+            H[hq].wait_mark(grp.h, mark)                # only the gather that last read THIS z buffer must be done (R steps ago), not the latest one
+        H[hq].solve_device(B, d["x0"], d["xs"], d["obs"], obs_kind, d_z0, o["z"], o["obj"], o["st"], o["it"], o["kkt"])
         if grp.active and gather:
             # the all-gather of this step's trajectories runs on the communication handle's stream behind this solve, while the
-            # younger solves of the other handles keep the GPU busy
-            grp.h.wait_for(H[hq])
-            grp.h.allgather(z_bufs[hq], z_all, B * nz)
+            # younger solves keep the GPU busy
+            H[hq].record(mark)
+            grp.h.wait_mark(H[hq], mark)
+            grp.h.allgather(o["z"], z_all, B * nz)
+            grp.h.record(mark)
 
     def fence():
         for h_ in H:
@@ -366,13 +404,22 @@ def main():
     dt = time.perf_counter() - t0
     if grp.active:      # the gathered block of this rank must equal what its last solve wrote
         got = z_all.download()[rank * B:(rank + 1) * B]
-        assert np.array_equal(got, z_bufs[(args.steps - 1) % F].download()), "all-gather result differs from the solver output"
+        assert np.array_equal(got, last["z"].download()), "all-gather result differs from the solver output"
     tms = [h_.timing() for h_ in H]
     tm = {"total_ms": sum(t_["total_ms"] for t_ in tms), "launches": sum(t_["launches"] for t_ in tms)}
 
     # every batch's status / iteration arrays hold its latest (identical, deterministic) result; weight by how often it ran
     uses = [args.steps // NB + (1 if q < args.steps % NB else 0) for q in range(NB)]
-    st_b = [d["st"].download() for d in D]; it_b = [d["it"].download() for d in D]
+    # (deterministic solves: a batch's result is the same every time it runs; read it from the set its latest solve wrote, unless a
+    # later step has reused that set — then from a fresh synchronous solve)
+    st_b = []; it_b = []
+    live = {id(OUT[k % HN][(k // HN) % R]): k % NB for k in range(args.steps)}           # set -> batch of the last step that wrote it
+    for q in range(NB):
+        o = last.get(q)
+        if o is None or live.get(id(o)) != q:
+            o = OUT[0][0]
+            bs.solve_device(B, D[q]["x0"], D[q]["xs"], D[q]["obs"], obs_kind, d_z0, o["z"], o["obj"], o["st"], o["it"], o["kkt"], sync=True)
+        st_b.append(o["st"].download()); it_b.append(o["it"].download())
     solved = sum(u * int((s_ == 0).sum()) for u, s_ in zip(uses, st_b))            # solved instances over all timed steps of this rank
     status = np.concatenate([s_ for u, s_ in zip(uses, st_b) if u]); iters = np.concatenate([i_ for u, i_ in zip(uses, it_b) if u])
     iters_per_launch = sum(u * float(i_.sum()) for u, i_ in zip(uses, it_b)) / max(1, args.steps)
@@ -387,13 +434,33 @@ def main():
     mx = grp.reduce([dt, dt_nogather or 0.0], "max"); dt_max, dt_nogather_max = float(mx[0]), float(mx[1])
     solved_all = int(round(float(grp.reduce([float(solved)], "sum")[0])))
 
+    # end to end through the host-pointer entry (mpcb_solve: pageable H2D of the inputs + solve + D2H of z, obj, status, iters, kkt),
+    # the PCIe-inclusive rate; never `value`
+    e2e = None
+    if rank == 0 and not args.warm:
+        bs.solve_batch(x0, xs, obs)
+        t1 = time.perf_counter(); reps_e = 3; ok_e = 0
+        for _ in range(reps_e):
+            ok_e += int((bs.solve_batch(x0, xs, obs)["status"] == 0).sum())
+        dte = (time.perf_counter() - t1) / reps_e
+        e2e = {"value": ok_e / reps_e / dte, "unit": "solves/s", "ms_per_call": 1e3 * dte,
+               "what": "mpcb_solve with host pointers, one call at a time: H2D of x0/xs/obs + both passes + D2H of z, obj, status, iters, kkt"}
+
     if rank == 0:
-        kernel_ms = tm["total_ms"] / max(1, tm["launches"])
-        abytes = algorithmic_bytes_per_solve(nx, nz, int(obs[0].size)) * B
+        launches = max(1, tm["launches"])
+        kernel_ms = tm["total_ms"] / launches
+        inst_per_launch = B * args.steps / launches                                # a launch = one chunk of the batch on one lane (both passes)
+        with_z0 = d_z0 is not None
+        bytes_solve = algorithmic_bytes_per_solve(nx, nz, int(obs[0].size), with_z0)
+        abytes = bytes_solve * inst_per_launch
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
         it_ok = iters[status == 0]
-        flops = (147e3 if cfg.model == _abi.MODEL_DYN else 56e3) * iters_per_launch   # ~56 kflop (kin N=30) / ~147 kflop (dyn N=40) per iteration
-        traffic, traffic_src = measured_traffic(workload)
+        flop_iter = 147e3 if cfg.model == _abi.MODEL_DYN else 56e3                  # ~56 kflop (kin N=30) / ~147 kflop (dyn N=40) per iteration
+        flops_model = flop_iter * iters_per_launch / B * inst_per_launch            # model flops of one launch
+        ctr = measured_counters(workload)
+        flops_ctr = (ctr["fp64_flop_per_launch"] / B * inst_per_launch) if ctr.get("fp64_flop_per_launch") else None
+        traffic = (ctr["bytes_per_launch"] / B * inst_per_launch) if ctr.get("bytes_per_launch") else None
+        flops_used = flops_ctr if flops_ctr else flops_model
         kk = ("dyn" if cfg.model == _abi.MODEL_DYN else "kin", 1 if cfg.n_obs <= 1 else 3)
         kname = ("mpcb_kernel_%s<%d>" % kk) + ((" + mpcb_kernel_%s_resto<%d> (one solve = first pass + restoration pass, timed together)" % kk) if cfg.restoration else "")
         out = {
@@ -405,22 +472,29 @@ def main():
                        "status_histogram_rank0": {str(k): int(v) for k, v in enumerate(np.bincount(status, minlength=7))},
                        "iters_mean_solved": float(it_ok.mean()) if len(it_ok) else None, "iters_max": int(iters.max()),
                        "iters_share_of_unsolved": float(iters[status != 0].sum() / max(1, iters.sum())),
-                       "restoration": bool(cfg.restoration),
-                       "launches_in_flight": F, "tol": cfg.tol,
+                       "restoration": bool(cfg.restoration), "integrator": "rk4" if cfg.integrator == _abi.INT_RK4 else "euler",
+                       "solver_handles": HN, "launch_lanes_per_handle": F, "launches_per_step": launches / args.steps, "tol": cfg.tol,
                        "collective": "RCCL all-gather of z per step inside libmpcbatch (mpcb_allgather), overlapped with the next steps' solves" if grp.active else "none",
                        "value_without_gather": (solved_all / dt_nogather_max) if dt_nogather else None,
                        "multi_gpu_note": "no N > 1 number has been measured on hardware by the builder (one-GPU boxes only); the driver's SCALE run is the measurement",
-                       "parity": PARITY_NOTE},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": kname, "kernel_ms_avg": kernel_ms,
-                         "algorithmic_bytes_per_launch": abytes,
-                         "achieved_over_wall_clock": abytes * args.steps / dt_max / 1e9,   # launches overlap (launches_in_flight): each one lasts longer than a step
-                         "note": "compulsory I/O is 3072 B/solve; the solve is LDS-resident, bound by FP64 VALU issue and the serial "
-                                 "Riccati chain, not by HBM (SURVEY.md F10, DESIGN.md §5)"},
-            "roofline_fp64": {"bound": "fp64_valu", "achieved": flops * args.steps / dt_max / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": flops * args.steps / dt_max / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                              "model": "56 kflop (kin) / 147 kflop (dyn) x interior-point iterations summed over the batch, per step, over the "
-                                       "wall clock of the timed region (launches overlap, so a launch lasts longer than a step)"},
+                       "parity": PARITY_NOTE, "parity_evidence": parity_evidence()},
+            # what binds: FP64 VALU issue (one wave per SIMD).  flops per launch from the committed PMC pass when there is one
+            # (SQ_INSTS_VALU_{ADD,MUL,TRANS}_F64 x 64 + FMA_F64 x 128), the 56/147 kflop-per-iteration model next to it
+            "roofline": {"bound": "fp64_valu_issue", "achieved": flops_used / (kernel_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops_used / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                         "flop_per_launch": flops_used, "flop_source": ("counters, " + ctr["source"]) if flops_ctr else "model (no committed PMC pass for this workload)",
+                         "flop_per_launch_model": flops_model, "traffic": traffic, "traffic_source": ctr.get("source"),
+                         "kernel": kname, "kernel_ms_avg": kernel_ms, "instances_per_launch": inst_per_launch,
+                         "achieved_over_wall_clock": flops_used * launches / dt_max / 1e12,   # launches overlap: each one lasts longer than its share of a step
+                         "frac_over_wall_clock": flops_used * launches / dt_max / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                         "valu_busy": ctr.get("valu_busy"), "wait_any": ctr.get("wait_any"),
+                         "note": "peak = FP64 vector rate of the chip (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz); the solve is LDS-resident and "
+                                 "bound by instruction issue at one wave per SIMD, not by HBM (SURVEY.md F10, DESIGN.md §5)"},
+            "roofline_hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                             "traffic": traffic, "algorithmic_bytes_per_launch": abytes, "algorithmic_bytes_per_solve": bytes_solve,
+                             "achieved_over_wall_clock": abytes * launches / dt_max / 1e9,
+                             "note": "compulsory I/O of the inputs actually passed (%s z0): x0, xs, obs in; z, obj, status, iters out" % ("with" if with_z0 else "no")},
+            "end_to_end": e2e,
         }
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, x0, xs, obs)

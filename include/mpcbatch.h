@@ -21,9 +21,12 @@
  *     z[2N + nx*k + s] = X[s,k]                                  CMOM/MPC_CBF_optimize_kin.py:160-161,250
  *   - constraint row order (g, lbg, ubg) is the reference's       CMOM/MPC_CBF_optimize_kin.py:107-132,190-247
  *   - per-instance solver outcome goes to status[] (MPCB_ST_*), never to the return code.
- *   - one handle = one device + one stream; calls on one handle must be serialised by the caller.  Distinct handles are
- *     independent: their launches overlap on the GPU, which is how throughput is kept up while the slowest instances of
- *     a launch finish (bench.py keeps three handles in flight).
+ *   - one handle = one device + one stream (+ optional launch lanes, mpcb_set_inflight); calls on one handle must be
+ *     serialised by the caller (one host thread at a time).  A launch ends with its slowest instance, so throughput needs
+ *     several launches in flight: mpcb_set_inflight(h, k) lets consecutive asynchronous mpcb_solve_device calls of ONE handle
+ *     overlap (bench.py's default: one handle, six lanes); distinct handles are independent as well.
+ *   - buffers of solves that are in flight at the same time (lanes, or several handles) must be distinct: in particular the
+ *     status array, through which the two passes of a solve communicate.
  */
 #ifndef MPCBATCH_H
 #define MPCBATCH_H
@@ -177,6 +180,17 @@ int mpcb_solve_device(mpcb_handle* h, int32_t B,
                       double* d_z, double* d_obj, int32_t* d_status, int32_t* d_iters, double* d_kkt,
                       double* d_lam_g, double* d_lam_x, int32_t sync);
 
+/* Launch lanes.  k = 1 (the default): every call is queued on the handle's one stream, in order.  k > 1: the handle owns k - 1
+ * further streams, and asynchronous mpcb_solve_device calls (sync = 0) go to the lanes in turn, call j on lane j mod k: up to k
+ * consecutive solves are in flight together, so the SIMDs that the slowest instances of one launch leave idle are filled by the
+ * next launches — inside one handle.  Calls j and j + k share a lane and are ordered; calls closer than k apart may run
+ * concurrently: they must not share output buffers (rotate k sets) nor consume each other's output (a warm-start chain needs
+ * mpcb_sync, mpcb_event_*, or k = 1).  Work queued earlier on the handle (uploads, scene sampling) happens before a lane's
+ * launch; every other entry point (mpcb_sync, mpcb_dev_download / _upload, mpcb_allgather, mpcb_stream_wait, mpcb_solve,
+ * mpcb_closed_loop ...) waits for all lanes first and runs on the handle's own stream.  Results do not depend on k (bit-identical). */
+#define MPCB_INFLIGHT_MAX 8
+int mpcb_set_inflight(mpcb_handle* h, int32_t k);
+
 /* Closed loop on the device: `steps` receding-horizon iterations of  solve -> apply U_0 with the plant
  * x0 <- x0 + T f(x0,U_0) -> shift warm start [-> advance obstacles]   (main_cbf_kin_c_sim.py:87-123,16-26;
  * main_cbf_kin_c_sim_pre.py:98-106; with model = MPCB_MODEL_DYN the loop of main_cbf_dyn_c_sim.py:75-108, plant = the dyn
@@ -268,6 +282,15 @@ int mpcb_sync(mpcb_handle* h);
 /* h's stream waits (on the device, the host does not block) for everything queued so far on other's stream: lets work of
  * several handles be chained, e.g. an all-gather on a communication handle behind the solve of a solver handle */
 int mpcb_stream_wait(mpcb_handle* h, mpcb_handle* other);
+
+/* Fine-grained ordering between handles of one device (e.g. solves on a solver handle, all-gathers on a communication handle,
+ * a ring of z buffers): mpcb_event_record(h, slot) marks "everything queued so far on h, its lanes included" WITHOUT joining the
+ * lanes, so later launches of h keep running ahead; mpcb_event_wait(h, other, slot) makes h's stream — and with it every later
+ * lane launch of h — wait for other's mark `slot` (no-op if that slot was never recorded).  mpcb_stream_wait above is the coarse
+ * form: everything queued so far on other. */
+#define MPCB_EVENT_SLOTS 16
+int mpcb_event_record(mpcb_handle* h, int32_t slot);
+int mpcb_event_wait(mpcb_handle* h, const mpcb_handle* other, int32_t slot);
 
 /* HIP-event timing of the solve kernel on the handle's stream since the last reset:
  * number of launches, total and last kernel milliseconds. */

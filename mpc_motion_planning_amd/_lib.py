@@ -6,7 +6,8 @@ import os
 from ._abi import MpcbConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmpcbatch.so")
+# MPCB_LIB names another build of the same library (diagnostic builds of tools/sync_ab.sh); there is still no fallback
+LIB_PATH = os.environ.get("MPCB_LIB") or os.path.join(_HERE, "lib", "libmpcbatch.so")
 
 _lib = None
 
@@ -28,6 +29,7 @@ SIGNATURES = {
     "mpcb_solve": (C.c_int, [_H, C.c_int32, _PD, _PD, _PD, C.c_int32, _PD, _PD, _PD, _PI, _PI, _PD, _PD, _PD]),
     "mpcb_solve_device": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "mpcb_set_inflight": (C.c_int, [_H, C.c_int32]),
     "mpcb_solve_trace": (C.c_int, [_H, _PD, _PD, _PD, C.c_int32, _PD, _PD, _PI, _PI, _PD]),
     "mpcb_closed_loop": (C.c_int, [_H, C.c_int32, C.c_int32, _PD, _PD, _PD, C.c_int32, C.c_int32, _PD, _PD, _PI, _PI]),
     "mpcb_sample_scenes": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -48,6 +50,8 @@ SIGNATURES = {
     "mpcb_dev_download": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_uint64]),
     "mpcb_sync": (C.c_int, [_H]),
     "mpcb_stream_wait": (C.c_int, [_H, _H]),
+    "mpcb_event_record": (C.c_int, [_H, C.c_int32]),
+    "mpcb_event_wait": (C.c_int, [_H, _H, C.c_int32]),
     "mpcb_timing": (C.c_int, [_H, C.c_int32, _PI, _PD, _PD]),
     "mpcb_model_rhs": (C.c_int, [C.POINTER(MpcbConfig), _PD, _PD, _PD]),
 }

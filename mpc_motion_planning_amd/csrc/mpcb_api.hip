@@ -11,7 +11,10 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mpcb_kernel_dyn.h"
@@ -166,7 +169,10 @@ struct SceneRng {
   __device__ int choice(int n) { return (int)(next() % (uint32_t)n); }
 };
 
-// one thread per scene; rejection sampling as mpc_motion_planning_amd/scenes.py (sample_c2 / sample_c3 / sample_c4), at most 256 draws
+// one thread per scene; whole-scene rejection sampling as mpc_motion_planning_amd/scenes.py (sample_c2 / sample_c3 / sample_c4): the same
+// population as the host samplers draw.  The loop is bounded (the exit every thread reaches), but far beyond what any accepted
+// configuration needs: the worst case, eight mutually separated C3 obstacles, accepts ~0.9 % of the draws, so 2^16 attempts
+// fail with probability < 1e-250 (the 256 of abi 2 left ~10 % of such scenes with overlapping obstacles, unflagged)
 __global__ __launch_bounds__(128) void mpcb_sample_kernel(const mpcb_config c, int kind, int B, uint64_t seed, uint64_t first,
                                                          double* __restrict__ x0, double* __restrict__ xs, double* __restrict__ obs) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(128) void mpcb_sample_kernel(const mpcb_config c, i
   SceneRng g(seed, first + (uint64_t)b);
   const int no = c.n_obs, nx = c.model == MPCB_MODEL_DYN ? 6 : 4;
   double e[6] = {0, 0, 0, 0, 0, 0}, o[MPCB_NOBS_MAX][6];
-  for (int attempt = 0; attempt < 256; ++attempt) {
+  for (int attempt = 0; attempt < (1 << 16); ++attempt) {
     bool ok = true;
     if (kind == MPCB_SCENES_C4) {
       e[0] = g.uniform(0, 30); e[1] = g.uniform(-0.5, 4.5); e[2] = g.uniform(-0.05, 0.05); e[3] = g.uniform(8, 20); e[4] = 0; e[5] = 0;
@@ -249,10 +255,17 @@ struct mpcb_handle {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;   // EV_RING pairs, created on first use
   int ev_head = 0, ev_pending = 0;                     // next pair to record into; pairs recorded and not yet harvested
   int launches = 0; double total_ms = 0, last_ms = 0;
-  bool lds_attr_set[2] = {false, false};               // hipFuncAttributeMaxDynamicSharedMemorySize applied to this handle's kernels (first pass, restoration pass)
-  // two-pass solve (cfg.restoration): hand-over records [B][WK_SIZE] and, when the caller passes no status array, the status
-  // column the passes communicate through
-  double* d_work = nullptr; int32_t* d_st_own = nullptr; int work_cap = 0;
+  // Launch lanes (mpcb_set_inflight): lane 0 IS the handle's stream; lanes 1..K-1 own a stream each.  An asynchronous
+  // mpcb_solve_device goes to the next lane(s) in turn, so that consecutive solves of one handle overlap on the GPU (the next
+  // launch fills the SIMDs the tail of the running one leaves idle) without the caller juggling handles.  Every lane has its own
+  // two-pass scratch: hand-over records [B][WK_SIZE] and, when the caller passes no status array, the status column the passes
+  // communicate through.  `done` marks the end of the lane's last launch; join_lanes() makes the handle's stream wait for it.
+  struct Lane { hipStream_t stream = nullptr; double* d_work = nullptr; int32_t* d_st_own = nullptr; int work_cap = 0; hipEvent_t done = nullptr; bool busy = false; };
+  std::vector<Lane> lanes;                             // lanes[0].stream == stream
+  int next_lane = 0;
+  hipEvent_t ev_fork = nullptr;                        // "everything queued so far on the handle's stream", awaited by a lane before it launches
+  std::vector<std::vector<hipEvent_t>> marks;          // mpcb_event_record: per slot one event per lane stream
+  std::vector<double> tgrid_host;                      // host copy of the time grid (handed to the peers of a device group)
   // multi-GPU: (a) this handle is rank `rank` of `world` processes (mpcb_comm_init_rank), or (b) it leads a group of
   // `peers.size()` devices of this process (mpcb_set_devices; peers[0] is a sibling handle on the leader's own device)
   ncclComm_t comm = nullptr; int world = 1, rank = 0;
@@ -284,12 +297,19 @@ struct Rccl {
 };
 std::string g_rccl_error;
 const Rccl* rccl() {
-  static Rccl R; static int state = 0;                       // 0 untried, 1 loaded, -1 failed
-  if (state == 0) {
-    void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!so) so = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!so) { g_rccl_error = dlerror() ? dlerror() : "dlopen failed"; state = -1; return nullptr; }
+  static Rccl R; static int state = 0;                       // 1 loaded, -1 failed
+  static std::once_flag once;                                // (handles are driven from several host threads)
+  std::call_once(once, [] {
+    // MPCB_RCCL_LIB names the library to load instead of the default search (a test points it at a missing file to exercise the error path)
+    const char* forced = std::getenv("MPCB_RCCL_LIB");
+    void* so = nullptr;
+    if (forced && *forced) so = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+    else {
+      so = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!so) so = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!so) { const char* e = dlerror(); g_rccl_error = e ? e : "dlopen failed"; state = -1; return; }
     bool ok = true;
 #define MPCB_SYM(field, name) do { R.field = (decltype(R.field))dlsym(so, name); if (!R.field) { ok = false; g_rccl_error = std::string("missing symbol ") + name; } } while (0)
     MPCB_SYM(GetUniqueId, "ncclGetUniqueId"); MPCB_SYM(CommInitRank, "ncclCommInitRank"); MPCB_SYM(CommInitAll, "ncclCommInitAll");
@@ -297,7 +317,7 @@ const Rccl* rccl() {
     MPCB_SYM(GroupStart, "ncclGroupStart"); MPCB_SYM(GroupEnd, "ncclGroupEnd"); MPCB_SYM(GetErrorString, "ncclGetErrorString");
 #undef MPCB_SYM
     state = ok ? 1 : -1;
-  }
+  });
   return state == 1 ? &R : nullptr;
 }
 #define NCCL_TRY(h, R, expr)                                                                     \
@@ -369,38 +389,86 @@ int collect_timing(mpcb_handle* h) {
   return MPCB_OK;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device), not of a handle: two handles of one process can
+// share an instantiation with different N.  The limit is therefore kept process-wide and only ever raised.
+std::mutex g_lds_mutex;
+std::map<std::pair<const void*, int>, size_t> g_lds_limit;
+
 template <class K>
-int launch_kernel(mpcb_handle* h, K kernel, const MpcbKArgs& a, size_t lds) {
-  if (lds > 48 * 1024 && !h->lds_attr_set[a.pass]) {   // once per handle and pass: one handle = one device + one NLP structure
-    HIP_TRY(h, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    h->lds_attr_set[a.pass] = true;
+int launch_kernel(mpcb_handle* h, hipStream_t stream, K kernel, const MpcbKArgs& a, size_t lds) {
+  if (lds > 48 * 1024) {
+    std::lock_guard<std::mutex> lock(g_lds_mutex);
+    size_t& cur = g_lds_limit[{(const void*)kernel, h->device}];
+    if (lds > cur) {
+      HIP_TRY(h, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      cur = lds;
+    }
   }
-  hipLaunchKernelGGL(kernel, dim3(a.B), dim3(64), lds, h->stream, a);
+  hipLaunchKernelGGL(kernel, dim3(a.B), dim3(64), lds, stream, a);
+  return MPCB_OK;
+}
+
+// the handle's stream waits for every lane that has a launch outstanding: called by everything that may consume the results of,
+// or overwrite the inputs of, asynchronous solves (downloads, uploads, collectives, the closed loop, mpcb_sync ...)
+int join_lanes(mpcb_handle* h) {
+  for (size_t i = 1; i < h->lanes.size(); ++i) {
+    auto& L = h->lanes[i];
+    if (L.busy) { HIP_TRY(h, hipStreamWaitEvent(h->stream, L.done, 0)); L.busy = false; }
+  }
+  return MPCB_OK;
+}
+
+int ensure_lanes(mpcb_handle* h, int k) {
+  if (h->lanes.empty()) { h->lanes.resize(1); h->lanes[0].stream = h->stream; }
+  while ((int)h->lanes.size() > k) {
+    auto& L = h->lanes.back();
+    if (L.d_work) (void)hipFree(L.d_work);
+    if (L.d_st_own) (void)hipFree(L.d_st_own);
+    if (L.done) (void)hipEventDestroy(L.done);
+    if (L.stream && L.stream != h->stream) (void)hipStreamDestroy(L.stream);
+    h->lanes.pop_back();
+  }
+  while ((int)h->lanes.size() < k) {
+    mpcb_handle::Lane L;
+    HIP_TRY(h, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    HIP_TRY(h, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+    h->lanes.push_back(L);
+  }
+  if (!h->ev_fork) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  h->next_lane = 0;
   return MPCB_OK;
 }
 
 bool two_pass(const mpcb_config& c) { return c.restoration != 0; }
 
-int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in) {
+// both passes of one solve on lane `lane_id` (0 = the handle's own stream)
+int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in, int lane_id = 0) {
   MpcbKArgs a = a_in;
   const size_t lds = lds_bytes(h->cfg, h->nz);
   if (lds > 160 * 1024) return fail(h, MPCB_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds);
   if (a.B == 0) return MPCB_OK;
+  if (h->lanes.empty()) { int rc = ensure_lanes(h, 1); if (rc != MPCB_OK) return rc; }
+  mpcb_handle::Lane& L = h->lanes[lane_id];
+  const hipStream_t stream = L.stream;
+  if (lane_id > 0) {                   // work queued earlier on the handle's stream (uploads, scene sampling) happens before this launch
+    HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(stream, h->ev_fork, 0));
+  }
   a.pass = 0; a.work = nullptr;
   if (two_pass(h->cfg)) {
-    if (a.B > h->work_cap) {       // grows with the largest batch seen (first call of a given size only)
-      HIP_TRY(h, hipStreamSynchronize(h->stream));
-      if (h->d_work) HIP_TRY(h, hipFree(h->d_work));
-      if (h->d_st_own) HIP_TRY(h, hipFree(h->d_st_own));
-      h->d_work = nullptr; h->d_st_own = nullptr; h->work_cap = 0;
-      HIP_TRY(h, hipMalloc(&h->d_work, (size_t)a.B * mpcbk::WK_SIZE * sizeof(double)));
-      HIP_TRY(h, hipMalloc(&h->d_st_own, (size_t)a.B * sizeof(int32_t)));
-      h->work_cap = a.B;
+    if (a.B > L.work_cap) {       // grows with the largest batch seen (first call of a given size only)
+      HIP_TRY(h, hipStreamSynchronize(stream));
+      if (L.d_work) HIP_TRY(h, hipFree(L.d_work));
+      if (L.d_st_own) HIP_TRY(h, hipFree(L.d_st_own));
+      L.d_work = nullptr; L.d_st_own = nullptr; L.work_cap = 0;
+      HIP_TRY(h, hipMalloc(&L.d_work, (size_t)a.B * mpcbk::WK_SIZE * sizeof(double)));
+      HIP_TRY(h, hipMalloc(&L.d_st_own, (size_t)a.B * sizeof(int32_t)));
+      L.work_cap = a.B;
     }
-    a.work = h->d_work;
+    a.work = L.d_work;
     if (!a.status) {                 // the passes communicate through the status column
       if (a.st_stride != 1) return fail(h, MPCB_E_INVALID, "a strided iteration history needs a status history");
-      a.status = h->d_st_own;
+      a.status = L.d_st_own;
     }
   }
   if (h->ev.empty()) {
@@ -409,23 +477,23 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in) {
   }
   if (h->ev_pending == mpcb_handle::EV_RING) { int rc = harvest_one(h); if (rc != MPCB_OK) return rc; }
   auto& evp = h->ev[h->ev_head];
-  HIP_TRY(h, hipEventRecord(evp.first, h->stream));
+  HIP_TRY(h, hipEventRecord(evp.first, stream));
   const int n = h->cfg.n_obs;
   int rc = MPCB_OK;
   if (h->cfg.model == MPCB_MODEL_DYN) {
-    if (n <= 1) rc = launch_kernel(h, mpcb_kernel_dyn<1>, a, lds);
-    else if (n <= 3) rc = launch_kernel(h, mpcb_kernel_dyn<3>, a, lds);
-    else if (n <= 5) rc = launch_kernel(h, mpcb_kernel_dyn<5>, a, lds);
-    else rc = launch_kernel(h, mpcb_kernel_dyn<8>, a, lds);
+    if (n <= 1) rc = launch_kernel(h, stream, mpcb_kernel_dyn<1>, a, lds);
+    else if (n <= 3) rc = launch_kernel(h, stream, mpcb_kernel_dyn<3>, a, lds);
+    else if (n <= 5) rc = launch_kernel(h, stream, mpcb_kernel_dyn<5>, a, lds);
+    else rc = launch_kernel(h, stream, mpcb_kernel_dyn<8>, a, lds);
   } else if (h->cfg.obs_mode == MPCB_OBS_DCBF && h->cfg.gamma < 1.0 - 1e-12 && n > 0) {   // general-gamma CBF rows
-    if (n == 1) rc = launch_kernel(h, mpcb_kernel_kin<1, true>, a, lds);
-    else if (n <= 3) rc = launch_kernel(h, mpcb_kernel_kin<3, true>, a, lds);
-    else rc = launch_kernel(h, mpcb_kernel_kin<8, true>, a, lds);
-  } else if (n == 0) rc = launch_kernel(h, mpcb_kernel_kin<0>, a, lds);
-  else if (n == 1) rc = launch_kernel(h, mpcb_kernel_kin<1>, a, lds);
-  else if (n <= 3) rc = launch_kernel(h, mpcb_kernel_kin<3>, a, lds);
-  else if (n <= 5) rc = launch_kernel(h, mpcb_kernel_kin<5>, a, lds);
-  else rc = launch_kernel(h, mpcb_kernel_kin<8>, a, lds);
+    if (n == 1) rc = launch_kernel(h, stream, mpcb_kernel_kin<1, true>, a, lds);
+    else if (n <= 3) rc = launch_kernel(h, stream, mpcb_kernel_kin<3, true>, a, lds);
+    else rc = launch_kernel(h, stream, mpcb_kernel_kin<8, true>, a, lds);
+  } else if (n == 0) rc = launch_kernel(h, stream, mpcb_kernel_kin<0>, a, lds);
+  else if (n == 1) rc = launch_kernel(h, stream, mpcb_kernel_kin<1>, a, lds);
+  else if (n <= 3) rc = launch_kernel(h, stream, mpcb_kernel_kin<3>, a, lds);
+  else if (n <= 5) rc = launch_kernel(h, stream, mpcb_kernel_kin<5>, a, lds);
+  else rc = launch_kernel(h, stream, mpcb_kernel_kin<8>, a, lds);
   if (rc != MPCB_OK) return rc;
   HIP_TRY(h, hipGetLastError());
   if (two_pass(h->cfg)) {
@@ -437,24 +505,25 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in) {
     if (lds2 > 160 * 1024) return fail(h, MPCB_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds2);
     const bool gen = h->cfg.obs_mode == MPCB_OBS_DCBF && h->cfg.gamma < 1.0 - 1e-12 && n > 0;
     if (dyn) {
-      if (n <= 1) rc = launch_kernel(h, mpcb_kernel_dyn_resto<1>, a, lds2);
-      else if (n <= 3) rc = launch_kernel(h, mpcb_kernel_dyn_resto<3>, a, lds2);
-      else if (n <= 5) rc = launch_kernel(h, mpcb_kernel_dyn_resto<5>, a, lds2);
-      else rc = launch_kernel(h, mpcb_kernel_dyn_resto<8>, a, lds2);
+      if (n <= 1) rc = launch_kernel(h, stream, mpcb_kernel_dyn_resto<1>, a, lds2);
+      else if (n <= 3) rc = launch_kernel(h, stream, mpcb_kernel_dyn_resto<3>, a, lds2);
+      else if (n <= 5) rc = launch_kernel(h, stream, mpcb_kernel_dyn_resto<5>, a, lds2);
+      else rc = launch_kernel(h, stream, mpcb_kernel_dyn_resto<8>, a, lds2);
     } else if (gen) {
-      if (n == 1) rc = launch_kernel(h, mpcb_kernel_kin_resto<1, true>, a, lds2);
-      else if (n <= 3) rc = launch_kernel(h, mpcb_kernel_kin_resto<3, true>, a, lds2);
-      else rc = launch_kernel(h, mpcb_kernel_kin_resto<8, true>, a, lds2);
-    } else if (n == 0) rc = launch_kernel(h, mpcb_kernel_kin_resto<0>, a, lds2);
-    else if (n == 1) rc = launch_kernel(h, mpcb_kernel_kin_resto<1>, a, lds2);
-    else if (n <= 3) rc = launch_kernel(h, mpcb_kernel_kin_resto<3>, a, lds2);
-    else if (n <= 5) rc = launch_kernel(h, mpcb_kernel_kin_resto<5>, a, lds2);
-    else rc = launch_kernel(h, mpcb_kernel_kin_resto<8>, a, lds2);
+      if (n == 1) rc = launch_kernel(h, stream, mpcb_kernel_kin_resto<1, true>, a, lds2);
+      else if (n <= 3) rc = launch_kernel(h, stream, mpcb_kernel_kin_resto<3, true>, a, lds2);
+      else rc = launch_kernel(h, stream, mpcb_kernel_kin_resto<8, true>, a, lds2);
+    } else if (n == 0) rc = launch_kernel(h, stream, mpcb_kernel_kin_resto<0>, a, lds2);
+    else if (n == 1) rc = launch_kernel(h, stream, mpcb_kernel_kin_resto<1>, a, lds2);
+    else if (n <= 3) rc = launch_kernel(h, stream, mpcb_kernel_kin_resto<3>, a, lds2);
+    else if (n <= 5) rc = launch_kernel(h, stream, mpcb_kernel_kin_resto<5>, a, lds2);
+    else rc = launch_kernel(h, stream, mpcb_kernel_kin_resto<8>, a, lds2);
     if (rc != MPCB_OK) return rc;
     HIP_TRY(h, hipGetLastError());
   }
-  HIP_TRY(h, hipEventRecord(evp.second, h->stream));
+  HIP_TRY(h, hipEventRecord(evp.second, stream));
   h->ev_head = (h->ev_head + 1) % mpcb_handle::EV_RING; ++h->ev_pending;
+  if (lane_id > 0) { HIP_TRY(h, hipEventRecord(L.done, stream)); L.busy = true; }
   return MPCB_OK;
 }
 
@@ -477,7 +546,7 @@ struct Carve {
 // one launch of the solve over B instances, everything resident on the handle's device, asynchronous on its stream
 int solve_on_device(mpcb_handle* h, int32_t B, const double* d_x0, const double* d_xs, const double* d_obs, int32_t obs_kind,
                     const double* d_z0, double* d_z, double* d_obj, int32_t* d_status, int32_t* d_iters, int32_t st_stride,
-                    double* d_kkt, double* d_lam_g, double* d_lam_x) {
+                    double* d_kkt, double* d_lam_g, double* d_lam_x, int lane_id = 0) {
   if (B < 0 || !d_x0 || !d_xs || !d_z) return fail(h, MPCB_E_INVALID, "B < 0 or a required pointer is NULL");
   if (h->cfg.n_obs > 0 && !d_obs) return fail(h, MPCB_E_INVALID, "n_obs = %d but obs is NULL", h->cfg.n_obs);
   if (obs_kind != MPCB_OBSIN_STATIC && obs_kind != MPCB_OBSIN_PREDICTED) return fail(h, MPCB_E_INVALID, "unknown obs_kind %d", obs_kind);
@@ -487,7 +556,21 @@ int solve_on_device(mpcb_handle* h, int32_t B, const double* d_x0, const double*
   a.want_mult = (d_lam_g || d_lam_x) ? 1 : 0; a.trace_instance = -1; a.trace = nullptr; a.st_stride = st_stride; a.tgrid = h->d_tgrid;
   a.x0 = d_x0; a.xs = d_xs; a.obs = d_obs; a.z0 = d_z0;
   a.z = d_z; a.obj = d_obj; a.kkt = d_kkt; a.lam_g = d_lam_g; a.lam_x = d_lam_x; a.status = d_status; a.iters = d_iters;
-  return launch_solve(h, a);
+  return launch_solve(h, a, lane_id);
+}
+
+// One asynchronous solve on the next lane in turn: call k on lane k mod K (K = 1: the handle's stream).  Up to K consecutive calls
+// are then in flight together, each a full-depth launch that fills the SIMDs the tails of the others leave idle; calls k and k + K
+// share a lane and are ordered.  Measured alternatives (C2, 4096 instances, MI355X): cutting every call into K chunks, chunk c on
+// lane c: 1.11 M solves/s against 1.48 M (only one batch's worth of workgroups is ever queued); cutting a lone synchronous call
+// into chunks: 5.5 ms per call against 4.2 ms for the single launch — so the host-pointer entries stay one launch on lane 0.
+int solve_next_lane(mpcb_handle* h, int32_t B, const double* d_x0, const double* d_xs, const double* d_obs, int32_t obs_kind,
+                    const double* d_z0, double* d_z, double* d_obj, int32_t* d_status, int32_t* d_iters, double* d_kkt,
+                    double* d_lam_g, double* d_lam_x) {
+  const int K = h->lanes.empty() ? 1 : (int)h->lanes.size();
+  const int lane = K == 1 ? 0 : h->next_lane;
+  if (K > 1) h->next_lane = (h->next_lane + 1) % K;
+  return solve_on_device(h, B, d_x0, d_xs, d_obs, obs_kind, d_z0, d_z, d_obj, d_status, d_iters, 1, d_kkt, d_lam_g, d_lam_x, lane);
 }
 
 }  // namespace
@@ -581,8 +664,14 @@ int mpcb_destroy(mpcb_handle* h) {
   if (h->d_red) (void)hipFree(h->d_red);
   if (h->ev_sync) (void)hipEventDestroy(h->ev_sync);
   if (h->d_tgrid) (void)hipFree(h->d_tgrid);
-  if (h->d_work) (void)hipFree(h->d_work);
-  if (h->d_st_own) (void)hipFree(h->d_st_own);
+  for (auto& L : h->lanes) {
+    if (L.stream && L.stream != h->stream) { (void)hipStreamSynchronize(L.stream); (void)hipStreamDestroy(L.stream); }
+    if (L.d_work) (void)hipFree(L.d_work);
+    if (L.d_st_own) (void)hipFree(L.d_st_own);
+    if (L.done) (void)hipEventDestroy(L.done);
+  }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  for (auto& m : h->marks) for (auto e : m) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return MPCB_OK;
@@ -647,21 +736,25 @@ int mpcb_set_bounds(mpcb_handle* h, const double* lbx, const double* ubx, int32_
   int rc = check_cfg(h, &c);
   if (rc != MPCB_OK) { h->cfg = saved; return rc; }
   h->cfg = c;
+  for (auto* q : h->peers) q->cfg = c;          // a device group solves every shard with the leader's bounds
   return MPCB_OK;
 }
 
 int mpcb_set_time_grid(mpcb_handle* h, const double* T_i, int32_t n) {
   if (!h) return MPCB_E_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
+  { int rc = join_lanes(h); if (rc != MPCB_OK) return rc; }
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   if (!T_i || n == 0) {
     if (h->d_tgrid) { HIP_TRY(h, hipFree(h->d_tgrid)); h->d_tgrid = nullptr; }
+    h->tgrid_host.clear();
   } else {
     if (n != h->cfg.N) return fail(h, MPCB_E_INVALID, "the time grid has %d entries, the NLP has N = %d stages", n, h->cfg.N);
     for (int i = 0; i < n; ++i) if (!(T_i[i] > 0) || !std::isfinite(T_i[i])) return fail(h, MPCB_E_INVALID, "T_%d = %g must be positive and finite", i, T_i[i]);
     if (!h->d_tgrid) HIP_TRY(h, hipMalloc(&h->d_tgrid, (size_t)h->cfg.N * sizeof(double)));
     HIP_TRY(h, hipMemcpy(h->d_tgrid, T_i, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
     h->T0 = T_i[0];
+    h->tgrid_host.assign(T_i, T_i + n);
   }
   for (auto* p : h->peers) { int rc = mpcb_set_time_grid(p, T_i, n); if (rc != MPCB_OK) return fail(h, rc, "device %d: %s", p->device, p->err.c_str()); }
   HIP_TRY(h, hipSetDevice(h->device));
@@ -672,10 +765,19 @@ int mpcb_solve_device(mpcb_handle* h, int32_t B, const double* d_x0, const doubl
                       const double* d_z0, double* d_z, double* d_obj, int32_t* d_status, int32_t* d_iters, double* d_kkt,
                       double* d_lam_g, double* d_lam_x, int32_t sync) {
   if (!h) return MPCB_E_INVALID;
-  int rc = solve_on_device(h, B, d_x0, d_xs, d_obs, obs_kind, d_z0, d_z, d_obj, d_status, d_iters, 1, d_kkt, d_lam_g, d_lam_x);
+  int rc = solve_next_lane(h, B, d_x0, d_xs, d_obs, obs_kind, d_z0, d_z, d_obj, d_status, d_iters, d_kkt, d_lam_g, d_lam_x);
   if (rc != MPCB_OK) return rc;
-  if (sync) HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (sync) return mpcb_sync(h);
   return MPCB_OK;
+}
+
+int mpcb_set_inflight(mpcb_handle* h, int32_t k) {
+  if (!h) return MPCB_E_INVALID;
+  if (k < 1 || k > MPCB_INFLIGHT_MAX) return fail(h, MPCB_E_INVALID, "inflight = %d outside 1..%d", k, MPCB_INFLIGHT_MAX);
+  int rc = mpcb_sync(h);
+  if (rc != MPCB_OK) return rc;
+  for (auto& m : h->marks) { for (auto e : m) (void)hipEventDestroy(e); m.clear(); }
+  return ensure_lanes(h, k);
 }
 
 }  // extern "C"
@@ -690,6 +792,7 @@ struct HostSolve {
   double *d_x0, *d_xs, *d_obs, *d_z0, *d_z, *d_obj, *d_kkt, *d_lg, *d_lx; int32_t *d_st, *d_it;
   int issue() {
     HIP_TRY(h, hipSetDevice(h->device));
+    { int rc = join_lanes(h); if (rc != MPCB_OK) return rc; }
     const int nx = h->nx, nz = h->nz, ng = h->ng, N = h->cfg.N;
     const size_t n_obs_d = (size_t)B * h->cfg.n_obs * 6 * (obs_kind == MPCB_OBSIN_PREDICTED ? N + 1 : 1);
     auto carve = [&](Carve& cv) {
@@ -716,6 +819,7 @@ struct HostSolve {
   }
   int collect() {
     HIP_TRY(h, hipSetDevice(h->device));
+    { int rc = join_lanes(h); if (rc != MPCB_OK) return rc; }
     const int nz = h->nz, ng = h->ng;
     hipStream_t s = h->stream;
     if (z) HIP_TRY(h, hipMemcpyAsync(z, d_z, (size_t)B * nz * 8, hipMemcpyDeviceToHost, s));
@@ -741,7 +845,7 @@ int solve_group(mpcb_handle* h, int32_t B, const double* x0, const double* xs, c
   for (int g = 0; g < G; ++g) {
     int64_t lo, hi; mpcb_shard_bounds(B, G, g, &lo, &hi);
     mpcb_handle* p = h->peers[g];
-    p->cfg = h->cfg;                                       // (bounds adopted by mpcb_set_bounds on the leader)
+    p->cfg = h->cfg;                                       // (bounds reach the peers in mpcb_set_bounds, the time grid in mpcb_set_time_grid / mpcb_set_devices; this keeps option edits of the leader in step)
     HostSolve& q = part[g];
     q = HostSolve{};
     q.h = p; q.B = (int32_t)(hi - lo); q.obs_kind = obs_kind;
@@ -758,10 +862,28 @@ int solve_group(mpcb_handle* h, int32_t B, const double* x0, const double* xs, c
       HIP_TRY(p, hipMalloc(&p->d_gather, need * sizeof(double)));
       p->gather_cap = need;
     }
-    if (q.B > 0) { int rc = q.issue(); if (rc != MPCB_OK) return fail(h, rc, "device %d: %s", p->device, p->err.c_str()); }
-    double* send = p->d_gather + (size_t)G * longest * nz;
-    if (q.B < longest) HIP_TRY(p, hipMemsetAsync(send, 0, (size_t)longest * nz * 8, p->stream));
-    if (q.B > 0) HIP_TRY(p, hipMemcpyAsync(send, q.d_z, (size_t)q.B * nz * 8, hipMemcpyDeviceToDevice, p->stream));
+  }
+  // Every shard is issued from its own host thread: the uploads come from pageable caller memory, where hipMemcpyAsync blocks
+  // its calling thread until the copy is staged — issued from one thread the shards would start one after the other.
+  {
+    std::vector<int> rcs(G, MPCB_OK);
+    auto issue_shard = [&](int g) {
+      mpcb_handle* p = h->peers[g]; HostSolve& q = part[g];
+      auto body = [&]() -> int {
+        HIP_TRY(p, hipSetDevice(p->device));
+        if (q.B > 0) { int rc = q.issue(); if (rc != MPCB_OK) return rc; }
+        double* send = p->d_gather + (size_t)G * longest * nz;
+        if (q.B < longest) HIP_TRY(p, hipMemsetAsync(send, 0, (size_t)longest * nz * 8, p->stream));
+        if (q.B > 0) HIP_TRY(p, hipMemcpyAsync(send, q.d_z, (size_t)q.B * nz * 8, hipMemcpyDeviceToDevice, p->stream));
+        return MPCB_OK;
+      };
+      rcs[g] = body();
+    };
+    std::vector<std::thread> th;
+    for (int g = 1; g < G; ++g) th.emplace_back(issue_shard, g);
+    issue_shard(0);
+    for (auto& t : th) t.join();
+    for (int g = 0; g < G; ++g) if (rcs[g] != MPCB_OK) return fail(h, rcs[g], "device %d: %s", h->peers[g]->device, h->peers[g]->err.c_str());
   }
   // one all-gather over xGMI: every device ends up with every shard's trajectories
   NCCL_TRY(h, R, R->GroupStart());
@@ -816,6 +938,7 @@ int mpcb_solve_trace(mpcb_handle* h, const double* x0, const double* xs, const d
   if (!h || !x0 || !xs || !z || !trace) return fail(h, MPCB_E_INVALID, "NULL argument");
   if (h->cfg.n_obs > 0 && !obs) return fail(h, MPCB_E_INVALID, "n_obs = %d but obs is NULL", h->cfg.n_obs);
   HIP_TRY(h, hipSetDevice(h->device));
+  { int rc = join_lanes(h); if (rc != MPCB_OK) return rc; }
   const int nx = h->nx, nz = h->nz, N = h->cfg.N;
   const size_t n_obs_d = (size_t)h->cfg.n_obs * 6 * (obs_kind == MPCB_OBSIN_PREDICTED ? N + 1 : 1);
   const size_t n_tr = (size_t)(h->cfg.max_iter + 1) * 8;
@@ -862,6 +985,7 @@ static int closed_loop_impl(mpcb_handle* h, int32_t B, int32_t steps, const doub
   const int predict = obs_motion == MPCB_OBSMOVE_PREDICTED;
   if (B == 0 || steps == 0) return MPCB_OK;
   HIP_TRY(h, hipSetDevice(h->device));
+  { int rc = join_lanes(h); if (rc != MPCB_OK) return rc; }
   const int nx = h->nx, nz = h->nz, N = h->cfg.N, no = h->cfg.n_obs;
   const size_t n_traj = predict ? (size_t)B * no * (N + 1) * 6 : 0;
   double *d_x0, *d_xs, *d_obs, *d_traj, *d_z0, *d_z, *d_xh, *d_uh; int32_t *d_st, *d_it;
@@ -951,6 +1075,7 @@ int mpcb_predict_obstacles(mpcb_handle* h, int32_t n, int32_t N, double dt, cons
   if (!h || n < 0 || N < 1 || !(dt > 0) || !obs || !traj) return fail(h, MPCB_E_INVALID, "bad argument");
   if (n == 0) return MPCB_OK;
   HIP_TRY(h, hipSetDevice(h->device));
+  { int rc = join_lanes(h); if (rc != MPCB_OK) return rc; }
   double *d_o, *d_t;
   auto carve = [&](Carve& cv) { d_o = cv.take<double>((size_t)n * 6); d_t = cv.take<double>((size_t)n * (N + 1) * 6); };
   { Carve dry{nullptr}; carve(dry); int rc = ensure_scratch(h, dry.bytes()); if (rc != MPCB_OK) return rc; }
@@ -1041,6 +1166,11 @@ int mpcb_set_devices(mpcb_handle* h, const int32_t* ids, int32_t n) {
   if (e != ncclSuccess) { for (auto* p : peers) mpcb_destroy(p); return fail(h, MPCB_E_DEVICE, "ncclCommInitAll: %s", R->GetErrorString(e)); }
   for (int i = 0; i < n; ++i) { peers[i]->comm = comms[i]; peers[i]->world = n; peers[i]->rank = i; }
   h->peers = peers; h->world = n; h->rank = 0;
+  // a time grid set before the group was formed goes to every new peer (bounds travel inside cfg, which mpcb_create copied)
+  if (!h->tgrid_host.empty()) {
+    for (auto* q : peers) { int rc = mpcb_set_time_grid(q, h->tgrid_host.data(), (int32_t)h->tgrid_host.size()); if (rc != MPCB_OK) return fail(h, rc, "device %d: %s", q->device, q->err.c_str()); }
+    HIP_TRY(h, hipSetDevice(h->device));
+  }
   return MPCB_OK;
 }
 
@@ -1054,6 +1184,7 @@ int mpcb_comm_info(const mpcb_handle* h, int32_t* world, int32_t* rank) {
 int mpcb_allgather(mpcb_handle* h, const double* d_send, double* d_recv, uint64_t count) {
   if (!h || !d_send || !d_recv) return fail(h, MPCB_E_INVALID, "NULL argument");
   HIP_TRY(h, hipSetDevice(h->device));
+  { int rc = join_lanes(h); if (rc != MPCB_OK) return rc; }
   if (h->world == 1 && !h->comm) {               // no group: the gather of one block is a copy
     if (d_recv != d_send) HIP_TRY(h, hipMemcpyAsync(d_recv, d_send, count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     return MPCB_OK;
@@ -1067,6 +1198,7 @@ int mpcb_allgather(mpcb_handle* h, const double* d_send, double* d_recv, uint64_
 int mpcb_allreduce(mpcb_handle* h, double* values, int32_t n, int32_t op) {
   if (!h || !values || n < 1 || n > 64 || (op != 0 && op != 1)) return fail(h, MPCB_E_INVALID, "bad argument (1 <= n <= 64, op 0 = sum, 1 = max)");
   HIP_TRY(h, hipSetDevice(h->device));
+  { int rc = join_lanes(h); if (rc != MPCB_OK) return rc; }
   if (!h->comm) { HIP_TRY(h, hipStreamSynchronize(h->stream)); return MPCB_OK; }
   const Rccl* R = rccl();
   HIP_TRY(h, hipMemcpyAsync(h->d_red, values, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1091,12 +1223,14 @@ int mpcb_dev_alloc(mpcb_handle* h, uint64_t bytes, void** dptr) {
 int mpcb_dev_free(mpcb_handle* h, void* dptr) {
   if (!h) return MPCB_E_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
+  { int rc = mpcb_sync(h); if (rc != MPCB_OK) return rc; }       // nothing in flight may still use the buffer
   HIP_TRY(h, hipFree(dptr));
   return MPCB_OK;
 }
 int mpcb_dev_upload(mpcb_handle* h, void* dptr, const void* src, uint64_t bytes) {
   if (!h || !dptr || !src) return MPCB_E_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
+  { int rc = join_lanes(h); if (rc != MPCB_OK) return rc; }
   HIP_TRY(h, hipMemcpyAsync(dptr, src, bytes, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MPCB_OK;
@@ -1104,6 +1238,7 @@ int mpcb_dev_upload(mpcb_handle* h, void* dptr, const void* src, uint64_t bytes)
 int mpcb_dev_download(mpcb_handle* h, void* dst, const void* dptr, uint64_t bytes) {
   if (!h || !dptr || !dst) return MPCB_E_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
+  { int rc = join_lanes(h); if (rc != MPCB_OK) return rc; }
   HIP_TRY(h, hipMemcpyAsync(dst, dptr, bytes, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MPCB_OK;
@@ -1111,6 +1246,7 @@ int mpcb_dev_download(mpcb_handle* h, void* dst, const void* dptr, uint64_t byte
 int mpcb_sync(mpcb_handle* h) {
   if (!h) return MPCB_E_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
+  { int rc = join_lanes(h); if (rc != MPCB_OK) return rc; }
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MPCB_OK;
 }
@@ -1119,9 +1255,30 @@ int mpcb_stream_wait(mpcb_handle* h, mpcb_handle* other) {
   if (!h || !other) return MPCB_E_INVALID;
   if (h->device != other->device) return fail(h, MPCB_E_INVALID, "mpcb_stream_wait: the handles live on different devices");
   HIP_TRY(h, hipSetDevice(h->device));
+  { int rc = join_lanes(other); if (rc != MPCB_OK) return fail(h, rc, "%s", other->err.c_str()); }   // "everything queued on other" includes its lanes
   if (!other->ev_sync) HIP_TRY(h, hipEventCreateWithFlags(&other->ev_sync, hipEventDisableTiming));
   HIP_TRY(h, hipEventRecord(other->ev_sync, other->stream));
   HIP_TRY(h, hipStreamWaitEvent(h->stream, other->ev_sync, 0));
+  return MPCB_OK;
+}
+
+int mpcb_event_record(mpcb_handle* h, int32_t slot) {
+  if (!h || slot < 0 || slot >= MPCB_EVENT_SLOTS) return fail(h, MPCB_E_INVALID, "slot outside 0..%d", MPCB_EVENT_SLOTS - 1);
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (h->lanes.empty()) { int rc = ensure_lanes(h, 1); if (rc != MPCB_OK) return rc; }
+  if (h->marks.empty()) h->marks.resize(MPCB_EVENT_SLOTS);
+  auto& m = h->marks[slot];
+  while (m.size() < h->lanes.size()) { hipEvent_t e; HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); m.push_back(e); }
+  for (size_t i = 0; i < h->lanes.size(); ++i) HIP_TRY(h, hipEventRecord(m[i], h->lanes[i].stream));   // the lanes are NOT joined: later launches stay free to run ahead
+  return MPCB_OK;
+}
+
+int mpcb_event_wait(mpcb_handle* h, const mpcb_handle* other, int32_t slot) {
+  if (!h || !other || slot < 0 || slot >= MPCB_EVENT_SLOTS) return fail(h, MPCB_E_INVALID, "NULL handle or slot outside 0..%d", MPCB_EVENT_SLOTS - 1);
+  if (h->device != other->device) return fail(h, MPCB_E_INVALID, "mpcb_event_wait: the handles live on different devices");
+  if (other->marks.empty() || other->marks[slot].empty()) return MPCB_OK;       // never recorded: nothing to wait for
+  HIP_TRY(h, hipSetDevice(h->device));
+  for (auto e : other->marks[slot]) HIP_TRY(h, hipStreamWaitEvent(h->stream, e, 0));
   return MPCB_OK;
 }
 

@@ -560,7 +560,12 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   }
 
   // ----- per-lane constants of the Riccati sweep: lane = entry (i, j) of the 8x8 stage block -------------------
+#ifdef MPCB_EXP_OPAQUE_SWEEP     // diagnostic build (tools/sync_ab.sh): the round-2 incident "asm barrier on the lane index in the sweep preamble"
+  const int lz = wv::opaque(lane);
+  const int ei = lz >> 3, ej = lz & 7;
+#else
   const int ei = lane >> 3, ej = lane & 7;
+#endif
   auto slotAB = [&](int r, int col) -> int {   // slot of entry [A B | aug](r, col), r < NA, col < NW, inside the stage's fw row
     if (r < NX) {
       if (col < NX) {

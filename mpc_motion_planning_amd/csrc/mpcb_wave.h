@@ -15,7 +15,11 @@
 // the solve functions are ALWAYS inlined into their kernels: out of line (hipcc 7.2 does that to the five largest instantiations on its
 // own) the LDS pointer becomes a generic pointer, every LDS access a FLAT instruction, and the restoration pass of kin<8, GEN> then
 // computed wrong costates on the GPU (tools/probe_fuzzcase.py 11 4) while the same source stepped on the CPU was right
+#ifdef MPCB_NOINLINE_SOLVE
+#define MPCB_DEVFN __device__
+#else
 #define MPCB_DEVFN __device__ __forceinline__
+#endif
 #define MPCB_HD __host__ __device__ inline
 
 namespace wv {
@@ -24,8 +28,11 @@ MPCB_DEV int lane() { return (int)threadIdx.x; }
 // lane followed by a load by another lane needs NO s_waitcnt and no s_barrier in between — only the compiler has to keep
 // the program order.  Wavefront-scope fences + wave_barrier do exactly that and emit no instruction; the loads that
 // follow are then waited for individually (counted lgkmcnt), so independent DS traffic stays in flight across a "sync".
-#ifdef MPCB_SYNC_BLOCK
+#if defined(MPCB_SYNC_BLOCK)
 MPCB_DEV void sync() { __syncthreads(); }
+#elif defined(MPCB_SYNC_WAITCNT)
+// diagnostic build (tools/sync_ab.sh): every sync drains the wave's outstanding memory operations
+MPCB_DEV void sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 #else
 MPCB_DEV void sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -83,7 +83,9 @@ class DeviceArray:
 
 
 class BatchSolver:
-    def __init__(self, cfg, device=0):
+    def __init__(self, cfg, device=0, inflight=1):
+        """inflight: launch lanes of the handle (mpcb_set_inflight).  With k > 1 consecutive asynchronous `solve_device` calls
+        overlap on the GPU and one large call is cut into chunks that do; results do not depend on it."""
         self.cfg = cfg.copy()
         self._h = C.c_void_p()
         rc = lib().mpcb_create(C.byref(self.cfg), device, C.byref(self._h))
@@ -92,6 +94,13 @@ class BatchSolver:
         self.nx, self.nz, self.ng = dims(self.cfg)
         self.N = self.cfg.N
         self.device = device
+        self.inflight = 1
+        if inflight != 1:
+            self.set_inflight(inflight)
+
+    def set_inflight(self, k):
+        check(lib().mpcb_set_inflight(self._h, int(k)), self._h)
+        self.inflight = int(k)
 
     def close(self):
         if self._h:
@@ -285,6 +294,14 @@ class BatchSolver:
     def wait_for(self, other):
         """This handle's stream waits (on the device) for everything queued so far on `other`'s stream."""
         check(lib().mpcb_stream_wait(self._h, other._h), self._h)
+
+    def record(self, slot):
+        """Mark "everything queued so far on this handle" in event slot `slot` (mpcb_event_record)."""
+        check(lib().mpcb_event_record(self._h, int(slot)), self._h)
+
+    def wait_mark(self, other, slot):
+        """This handle's later work waits for `other`'s mark `slot` (mpcb_event_wait); no-op if never recorded."""
+        check(lib().mpcb_event_wait(self._h, other._h, int(slot)), self._h)
 
     def timing(self, reset=False):
         n = C.c_int32(); tot = C.c_double(); last = C.c_double()

@@ -93,13 +93,53 @@ class KinNlp:
             zc[i] = z[i]
         return g
 
-    def jac_g(self, z, h=1e-30):
+    def jac_g_dense(self, z, h=1e-30):
+        """One complex step per variable: the plain definition (nz evaluations of g)."""
         J = np.empty((self.ng, self.nz))
         zc = z.astype(complex)
         for i in range(self.nz):
             zc[i] += 1j * h
             J[:, i] = self.g(zc).imag / h
             zc[i] = z[i]
+        return J
+
+    _patterns = {}
+
+    def _pattern_key(self):
+        return (type(self).__name__, self.N, self.n_obs, getattr(self, "obs_mode", ""))
+
+    def jac_g(self, z, h=1e-30):
+        """The same Jacobian from a handful of evaluations: columns that share no row (variables three or more stages apart) are
+        perturbed together (Curtis-Powell-Reid colouring of the structural pattern, which is found once per NLP structure from two
+        dense Jacobians at random points and cached).  tests/test_oracle.py checks it against jac_g_dense."""
+        key = self._pattern_key()
+        if key not in KinNlp._patterns:
+            rng = np.random.default_rng(0)
+            P = np.zeros((self.ng, self.nz), bool)
+            for _ in range(2):
+                zr = z + rng.uniform(0.05, 0.5, self.nz) * rng.choice([-1.0, 1.0], self.nz)
+                P |= self.jac_g_dense(zr) != 0.0
+            groups = []                                  # greedy: a column joins the first group none of whose rows it touches
+            rows_of = []
+            for j in range(self.nz):
+                rj = P[:, j]
+                for gi, used in enumerate(rows_of):
+                    if not (used & rj).any():
+                        groups[gi].append(j); used |= rj
+                        break
+                else:
+                    groups.append([j]); rows_of.append(rj.copy())
+            KinNlp._patterns[key] = (P, [np.array(g_) for g_ in groups])
+        P, groups = KinNlp._patterns[key]
+        J = np.zeros((self.ng, self.nz))
+        zc = z.astype(complex)
+        for cols in groups:
+            zc[cols] += 1j * h
+            d = self.g(zc).imag / h
+            zc[cols] = z[cols]
+            for j in cols:
+                r = P[:, j]
+                J[r, j] = d[r]
         return J
 
 
@@ -189,6 +229,8 @@ class DynNlp:
         return np.concatenate([np.asarray(r).reshape(-1) for r in rows])
 
     grad_f = KinNlp.grad_f
+    jac_g_dense = KinNlp.jac_g_dense
+    _pattern_key = KinNlp._pattern_key
     jac_g = KinNlp.jac_g
 
     def convert_obstacle_multipliers(self, z, lam_g):

@@ -36,6 +36,26 @@ def lib():
     return _LIB
 
 
+def use_native_build():
+    """bench.py's cpu_baseline leg only: compile the oracle once more with -O3 -march=native for THE MACHINE THIS RUNS ON (a
+    temporary directory: such a binary must not travel between hosts) and make it the library solve() calls from now on.
+    The test-suite keeps the portable -O2 build, whose results the golden vectors were generated with (FMA contraction under
+    -march=native moves last digits).  Returns the flags used, or None when no compiler is at hand (the -O2 build stays)."""
+    global _LIB
+    import tempfile
+    flags = ["-O3", "-march=native", "-std=c++17", "-fPIC", "-fopenmp", "-shared", "-Wl,-Bsymbolic"]
+    so = os.path.join(tempfile.mkdtemp(prefix="mpcoracle_native_"), "libmpcoracle_native.so")
+    try:
+        subprocess.check_call(["g++"] + flags + ["-o", so, os.path.join(_HERE, "mpc_oracle.cpp")], stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    _LIB = C.CDLL(so)
+    _LIB.mpco_solve.restype = C.c_int
+    _LIB.mpco_default_config.restype = C.c_int
+    _LIB.mpco_dims.restype = C.c_int
+    return " ".join(flags[:2])
+
+
 def default_config(model=MODEL_KIN, N=30, T=0.1, n_obs=0):
     cfg = MpcbConfig()
     rc = lib().mpco_default_config(C.byref(cfg), C.c_int32(model), C.c_int32(N), C.c_double(T))

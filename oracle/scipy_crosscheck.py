@@ -42,3 +42,50 @@ def solve_slsqp(nlp, z0, scale=1e-4, maxiter=1000):
         s = minimize(lambda z: scale * nlp.f(z), z0, jac=lambda z: scale * nlp.grad_f(z), bounds=list(zip(lb, ub)), constraints=cons,
                      method="SLSQP", options=dict(maxiter=maxiter, ftol=1e-16))
     return s.x, float(nlp.f(s.x)), s
+
+
+def min_violation_slsqp(nlp, z0, maxiter=400):
+    """Independent audit of an "infeasible" verdict: SLSQP on the pure feasibility problem of `nlp`
+        minimise sum(s)   s.t.  equality rows and two-sided rows of g as they are, one-sided rows  g_i(z) + s_i >= lbg_i,  s >= 0,  lbx <= z <= ubx
+    (the one-sided rows are the obstacle rows: the only reverse-convex ones).  Returns (sum(s) at the solution, largest violation
+    of ANY row or box at the z found, z).  A value <= 1e-8 means a feasible point exists and the verdict was wrong."""
+    eq = nlp.lbg == nlp.ubg
+    two = ~eq & np.isfinite(nlp.lbg) & np.isfinite(nlp.ubg)
+    one = ~eq & np.isfinite(nlp.lbg) & ~np.isfinite(nlp.ubg)
+    assert not (~eq & ~np.isfinite(nlp.lbg)).any()
+    nz, ns = nlp.nz, int(one.sum())
+    g0 = nlp.g(np.asarray(z0, float))
+    s0 = np.maximum(0.0, (nlp.lbg - g0)[one]) + 1e-3
+    y0 = np.concatenate([np.asarray(z0, float), s0])
+
+    def parts(y):
+        return y[:nz], y[nz:]
+
+    def c_eq(y):
+        z, _ = parts(y); return (nlp.g(z) - nlp.lbg)[eq]
+
+    def j_eq(y):
+        z, _ = parts(y); return np.hstack([nlp.jac_g(z)[eq], np.zeros((int(eq.sum()), ns))])
+
+    def c_in(y):
+        z, s = parts(y); g = nlp.g(z)
+        return np.concatenate([(g - nlp.lbg)[two], (nlp.ubg - g)[two], (g - nlp.lbg)[one] + s])
+
+    def j_in(y):
+        z, _ = parts(y); J = nlp.jac_g(z)
+        return np.vstack([np.hstack([J[two], np.zeros((int(two.sum()), ns))]), np.hstack([-J[two], np.zeros((int(two.sum()), ns))]),
+                          np.hstack([J[one], np.eye(ns)])])
+
+    lb = np.concatenate([np.where(np.isfinite(nlp.lbx), nlp.lbx, -1e20), np.zeros(ns)])
+    ub = np.concatenate([np.where(np.isfinite(nlp.ubx), nlp.ubx, 1e20), np.full(ns, 1e20)])
+    grad = np.concatenate([np.zeros(nz), np.ones(ns)])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = minimize(lambda y: y[nz:].sum(), y0, jac=lambda y: grad, bounds=list(zip(lb, ub)),
+                     constraints=[dict(type="eq", fun=c_eq, jac=j_eq), dict(type="ineq", fun=c_in, jac=j_in)], method="SLSQP",
+                     options=dict(maxiter=maxiter, ftol=1e-14))
+    z, s = parts(r.x)
+    g = nlp.g(z)
+    viol = max(np.maximum(0, np.maximum(nlp.lbg - g, g - nlp.ubg)).max(), np.maximum(0, np.maximum(nlp.lbx - z, z - nlp.ubx)).max())
+    return float(s.sum()), float(viol), z

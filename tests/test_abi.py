@@ -74,3 +74,25 @@ def test_shard_bounds_of_the_library_match_the_host_rule():
     assert _lib.lib().mpcb_shard_bounds(10, 2, 2, C.byref(lo), C.byref(hi)) == _abi.E_INVALID
     w, r = C.c_int32(), C.c_int32()
     assert _lib.lib().mpcb_comm_info(None, C.byref(w), C.byref(r)) == _abi.E_INVALID
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """librccl is loaded on first use; when it cannot be loaded the group entry points return MPCB_E_DEVICE with a message
+    (abi 2 assigned a NULL dlerror() to a std::string there).  Own process: the load is attempted once per process."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r)\n"
+            "from mpc_motion_planning_amd import _lib, _abi\n"
+            "L = _lib.lib(); buf = C.create_string_buffer(128)\n"
+            "rc = L.mpcb_comm_unique_id(C.cast(buf, C.c_void_p)); msg = L.mpcb_last_error(None)\n"
+            "rc2 = L.mpcb_comm_unique_id(C.cast(buf, C.c_void_p))\n"
+            "print(rc, rc2, msg.decode())\n" % ROOT)
+    env = dict(os.environ, MPCB_RCCL_LIB="/nonexistent/librccl.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rc, rc2, msg = out.stdout.strip().split(" ", 2)
+    assert int(rc) == _abi.E_DEVICE and int(rc2) == _abi.E_DEVICE and "librccl" in msg and "nonexistent" in msg
+
+
+def test_inflight_argument_checks_need_no_device():
+    assert _lib.lib().mpcb_set_inflight(None, 2) == _abi.E_INVALID

@@ -16,7 +16,9 @@ def _worker(rank, world, port, B, out_dir):
     import torch.distributed as dist
     from oracle import oracle
     from mpc_motion_planning_amd import scenes
-    from mpc_motion_planning_amd.sharding import shard, shard_bounds, gather_rows
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from mpc_motion_planning_amd.sharding import shard, shard_bounds
+    from dist_helpers import gather_rows
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = oracle.default_config(N=30, n_obs=1); cfg.init_rollout = 1; cfg.mu_init = 10.0

@@ -556,6 +556,51 @@ def test_two_handles_in_flight_give_the_same_results(gpu_solver_factory):
         assert np.array_equal(d[name]["z"].download(), r["z"])                            # bit for bit: the kernel is deterministic
 
 
+def test_launch_lanes_of_one_handle_give_the_same_results(gpu_solver_factory):
+    """mpcb_set_inflight: consecutive asynchronous solves of one handle go to its lanes in turn and overlap.  Results must not
+    depend on the number of lanes — bit for bit — and the marks (mpcb_event_record / _wait) must order a consumer on another handle behind exactly the solve they follow."""
+    cfg = default_config(N=30, n_obs=1)
+    B = 3000
+    x0, xs, obs = scenes.sample_c2(B, seed=81); x1, _, ob1 = scenes.sample_c2(B, seed=82)
+    one = gpu_solver_factory(cfg)
+    r = [one.solve_batch(x0, xs, obs, multipliers=True), one.solve_batch(x1, xs, ob1)]
+    w0 = one.solve_batch(x0, xs, obs, z0=r[0]["z"])                                       # warm start from the solution
+    K = 3
+    h = gpu_solver_factory(cfg, inflight=K)
+    assert h.inflight == K
+    with pytest.raises(Exception):
+        h.set_inflight(99)
+    g = h.solve_batch(x0, xs, obs, multipliers=True)                                      # host pointers: the handle's own stream
+    for k in ("z", "status", "iters", "obj", "kkt", "lam_g", "lam_x"):
+        assert np.array_equal(g[k], r[0][k]), k
+    dx = [h.device_array((B, 4)).upload(a) for a in (x0, x1)]; dxs = h.device_array((B, 4)).upload(xs)
+    dob = [h.device_array(a.shape).upload(a) for a in (obs, ob1)]
+    ring = [dict(z=h.device_array((B, 184)), st=h.device_array((B,), np.int32), it=h.device_array((B,), np.int32)) for _ in range(K)]
+    for j in range(4 * K + 1):                                                             # back to back, K sets of output buffers in rotation
+        q = ring[j % K]
+        h.solve_device(B, dx[j % 2], dxs, dob[j % 2], _abi.OBSIN_STATIC, None, q["z"], None, q["st"], q["it"], None)
+    h.sync()
+    for s_ in range(K):                                                                    # the last call that wrote set s_ was call j_ = ...
+        j_ = max(j for j in range(4 * K + 1) if j % K == s_)
+        ref = r[j_ % 2]
+        assert np.array_equal(ring[s_]["z"].download(), ref["z"]) and np.array_equal(ring[s_]["st"].download(), ref["status"])
+        assert np.array_equal(ring[s_]["it"].download(), ref["iters"])
+    # a warm-start chain across lanes needs an ordering: mark after the producer, wait before the consumer
+    z2 = h.device_array((B, 184))
+    h.solve_device(B, dx[0], dxs, dob[0], _abi.OBSIN_STATIC, None, ring[0]["z"], None, ring[0]["st"], ring[0]["it"], None)
+    h.record(5); h.wait_mark(h, 5)
+    h.solve_device(B, dx[0], dxs, dob[0], _abi.OBSIN_STATIC, ring[0]["z"], z2, None, ring[1]["st"], ring[1]["it"], None)
+    # a consumer on another handle, ordered by a mark: it copies z2 (gather of one = copy) after exactly that solve
+    c = gpu_solver_factory(cfg); out = c.device_array((B, 184))
+    h.record(3); c.wait_mark(h, 3); c.allgather(z2, out, B * 184)
+    h.solve_device(B, dx[1], dxs, dob[1], _abi.OBSIN_STATIC, None, ring[2]["z"], None, ring[2]["st"], ring[2]["it"], None)   # younger work of h runs ahead
+    c.sync(); h.sync()
+    assert np.array_equal(out.download(), w0["z"]) and np.array_equal(z2.download(), w0["z"])
+    assert np.array_equal(ring[2]["z"].download(), r[1]["z"])
+    h.set_inflight(1)
+    assert np.array_equal(h.solve_batch(x1, xs, ob1)["z"], r[1]["z"])
+
+
 def test_multi_gpu_paths_inside_the_library(gpu_solver_factory):
     """include/mpcbatch.h "multi-GPU": a device group of this process (mpcb_set_devices -> ncclCommInitAll; shards, solves,
     all-gathers z) and the one-process-per-GPU group (mpcb_comm_init_rank) on the devices that are visible — on a one-GPU box

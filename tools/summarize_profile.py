@@ -17,7 +17,7 @@ if bench:
         bench.get("value"), bench.get("unit"), bench.get("ms_per_step", float("nan")), bench.get("roofline", {}).get("kernel_ms_avg", float("nan"))))
 # one solve = two launches since round 2 (first pass + restoration pass): every kernel gets its own block, taken from its last dispatch
 allv = {}
-for g in "abcd":
+for g in "abcde":
     files = glob.glob(os.path.join(out, "pmc" + g, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         continue
@@ -54,11 +54,19 @@ for k, vals in allv.items():
             k, 100 * vals.get("SQ_ACTIVE_INST_VALU", 0) / wc, 100 * vals.get("SQ_ACTIVE_INST_LDS", 0) / wc,
             100 * vals.get("SQ_WAIT_ANY", 0) / wc, 100 * vals.get("SQ_WAIT_INST_LDS", 0) / wc,
             100 * vals.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, vals.get("SQ_LDS_IDX_ACTIVE", 0))))
+fp64 = sum(64.0 * (v.get("SQ_INSTS_VALU_ADD_F64", 0.0) + v.get("SQ_INSTS_VALU_MUL_F64", 0.0) + v.get("SQ_INSTS_VALU_TRANS_F64", 0.0)) + 128.0 * v.get("SQ_INSTS_VALU_FMA_F64", 0.0)
+           for v in allv.values())
+if fp64:
+    lines.append("")
+    lines.append("FP64 operations per solve launch (wave instructions x 64 lanes, FMA counted twice; both passes): %.4g flop" % fp64)
 if bench and (tot_f or tot_w):
     # measured HBM bytes per solve (both launches), corrected as the guide prescribes; bench.py reports it as roofline.traffic (offline)
     wl = bench.get("config", {}).get("workload", "")
-    json.dump({"workload_key": wl.split(":")[0], "workload": wl, "fetch_kib": tot_f, "write_kib": tot_w,
-               "bytes_per_launch": (2 * tot_f + tot_w) * 1024.0},
+    first = next((v for k, v in allv.items() if "resto" not in k and v.get("SQ_WAVE_CYCLES")), {})
+    wc = first.get("SQ_WAVE_CYCLES", 0.0)
+    json.dump({"workload_key": wl.split(":")[0], "workload": wl, "round": sys.argv[2] if len(sys.argv) > 2 else None, "fetch_kib": tot_f, "write_kib": tot_w,
+               "bytes_per_launch": (2 * tot_f + tot_w) * 1024.0, "fp64_flop_per_launch": fp64 or None,
+               "valu_busy": (first.get("SQ_ACTIVE_INST_VALU", 0.0) / wc) if wc else None, "wait_any": (first.get("SQ_WAIT_ANY", 0.0) / wc) if wc else None},
               open(os.path.join(out, "traffic.json"), "w"))
 open(os.path.join(out, "pmc.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
