@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MPCB_ABI_VERSION 2
+#define MPCB_ABI_VERSION 3
 
 /* return codes */
 #define MPCB_OK              0
@@ -57,6 +57,9 @@ extern "C" {
                                     Problem may be infeasible", return_status Infeasible_Problem_Detected) */
 #define MPCB_ST_RESTO_FAILED  6  /* the restoration phase itself found no acceptable step / ran into max_iter without reducing
                                     the violation (IPOPT "Restoration_Failed") */
+/*      7 is used internally between the two passes of a solve and never returned */
+#define MPCB_ST_ACCEPTABLE    8  /* acceptable_iter iterations in a row met the acceptable_* tolerances (IPOPT "Solved To Acceptable
+                                    Level"): the only two options the reference sets belong to this test, kin.py:252-253 */
 
 /* models                                                     reference */
 #define MPCB_MODEL_KIN 0      /* 4-state kinematic bicycle     CMOM/MPC_CBF_optimize_kin.py:153-156 */
@@ -122,6 +125,24 @@ typedef struct mpcb_config {
   double   bound_frac;        /* 0.01 (kappa_2) */
   double   bound_relax;       /* 1e-8 (bound_relax_factor) */
   double   max_gradient;      /* 100 (nlp_scaling_max_gradient) */
+  /* termination as IPOPT's OptimalityErrorConvergenceCheck does it: "optimal" needs the scaled error <= tol AND three UNSCALED
+     gates (the objective scaling of these NLPs is ~1e-4, so the complementarity gate can bind); "acceptable" after acceptable_iter
+     iterations in a row within the acceptable_* tolerances whose objective changed by less than acceptable_obj_change_tol */
+  double   dual_inf_tol;                 /* 1      max-norm of the unscaled dual infeasibility */
+  double   constr_viol_tol;              /* 1e-4   max-norm of the unscaled constraint violation */
+  double   compl_inf_tol;                /* 1e-4   max-norm of the unscaled complementarity */
+  double   acceptable_tol;               /* IPOPT 1e-6; the reference sets 1e-8               kin.py:252 */
+  double   acceptable_obj_change_tol;    /* IPOPT 1e20; the reference sets 1e-6               kin.py:253 */
+  double   acceptable_constr_viol_tol;   /* 1e-2 */
+  double   acceptable_dual_inf_tol;      /* 1e10 */
+  double   acceptable_compl_inf_tol;     /* 1e-2 */
+  int32_t  acceptable_iter;              /* 15; 0 switches the acceptable test off */
+  int32_t  second_start;                 /* 1 (mpcb_default_config): an instance whose solve from a roll-out start (init_rollout = 1) fails (no
+                                            acceptable step, a run of tiny steps, max_iter, numerics) is solved once more from the reference's own
+                                            first-step start z = 0 (main_cbf_kin_c_sim.py:47-50; dynamic model: 0 except vx = x0's, the tyre model
+                                            divides by vx), and only that second attempt enters the restoration phase; `iters` counts both
+                                            attempts, each has max_iter of its own.  Without a roll-out (init_rollout = 0: the start taken as
+                                            given, IPOPT's behaviour) there is one attempt, whatever this field says.  0: one attempt */
 } mpcb_config;
 
 typedef struct mpcb_handle mpcb_handle;

@@ -5,12 +5,13 @@ tests/test_abi.py checks sizeof and the exported symbols against the header.
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK, E_INVALID, E_BOUNDS, E_DEVICE, E_UNSUPPORTED = 0, -1, -2, -3, -4
 ST_SOLVED, ST_MAXITER, ST_LINESEARCH, ST_INFEASIBLE_X0, ST_NUMERIC, ST_INFEASIBLE, ST_RESTO_FAILED = 0, 1, 2, 3, 4, 5, 6
+ST_ACCEPTABLE = 8
 STATUS_NAMES = {0: "solved", 1: "max_iter", 2: "line_search", 3: "infeasible_x0", 4: "numeric", 5: "locally_infeasible",
-                6: "restoration_failed"}
+                6: "restoration_failed", 8: "acceptable"}
 MODEL_KIN, MODEL_DYN = 0, 1
 OBS_KEEPOUT, OBS_DCBF = 0, 1
 OBSIN_STATIC, OBSIN_PREDICTED = 0, 1
@@ -43,6 +44,10 @@ class MpcbConfig(C.Structure):
         ("Fymax_f", _d), ("Fymax_r", _d), ("aopt_f", _d), ("aopt_r", _d),
         ("tol", _d), ("mu_init", _d), ("bound_push", _d), ("bound_frac", _d), ("bound_relax", _d),
         ("max_gradient", _d),
+        ("dual_inf_tol", _d), ("constr_viol_tol", _d), ("compl_inf_tol", _d),
+        ("acceptable_tol", _d), ("acceptable_obj_change_tol", _d), ("acceptable_constr_viol_tol", _d),
+        ("acceptable_dual_inf_tol", _d), ("acceptable_compl_inf_tol", _d),
+        ("acceptable_iter", _i), ("second_start", _i),
     ]
 
     def copy(self):

@@ -95,7 +95,8 @@ __global__ __launch_bounds__(128) void mpcb_advance(const mpcb_config c, int B, 
   const int N = c.N, n_obs = c.n_obs;     // T: length of the executed step (cfg.T, or T_0 of the time grid)
   double* w = z0 + (size_t)b * nz;
   // the plan that is executed: this step's solution, or (hold) the previous plan kept in z0
-  const bool keep = hold && status && status[(size_t)b * st_stride] != MPCB_ST_SOLVED;
+  const int st_b = status ? status[(size_t)b * st_stride] : MPCB_ST_SOLVED;
+  const bool keep = hold && st_b != MPCB_ST_SOLVED && st_b != MPCB_ST_ACCEPTABLE;
   const double* zb = keep ? w : z + (size_t)b * nz;
   double* xb = x0 + (size_t)b * NX;
   const double u[2] = {zb[0], zb[1]};
@@ -339,6 +340,9 @@ int check_cfg(mpcb_handle* h, const mpcb_config* c) {
   if (c->n_obs < 0 || c->n_obs > MPCB_NOBS_MAX) return fail(h, MPCB_E_INVALID, "n_obs = %d outside 0..%d", c->n_obs, MPCB_NOBS_MAX);
   if (!(c->T > 0) || !(c->tol > 0) || c->max_iter < 0 || !(c->mu_init > 0)) return fail(h, MPCB_E_INVALID, "T, tol, mu_init must be > 0 and max_iter >= 0");
   if (!(c->veh_l > 0)) return fail(h, MPCB_E_INVALID, "veh_l must be > 0");
+  if (!(c->dual_inf_tol > 0) || !(c->constr_viol_tol > 0) || !(c->compl_inf_tol > 0) || c->acceptable_iter < 0 || !(c->acceptable_tol > 0) ||
+      !(c->acceptable_obj_change_tol >= 0) || !(c->acceptable_constr_viol_tol > 0) || !(c->acceptable_dual_inf_tol > 0) || !(c->acceptable_compl_inf_tol > 0))
+    return fail(h, MPCB_E_INVALID, "termination tolerances must be > 0 (mpcb_default_config sets IPOPT's defaults) and acceptable_iter >= 0");
   for (int i = 0; i < 2; ++i) if (!(c->R[i] > 0)) return fail(h, MPCB_E_INVALID, "R must be positive");
   if (c->obs_mode == MPCB_OBS_DCBF && !(c->gamma > 0.0 && c->gamma <= 1.0 + 1e-12))
     return fail(h, MPCB_E_INVALID, "discrete-CBF rows need 0 < gamma <= 1 (kin.py:235 uses 1.0), got %g", c->gamma);
@@ -352,6 +356,7 @@ int check_cfg(mpcb_handle* h, const mpcb_config* c) {
     return fail(h, MPCB_E_UNSUPPORTED, "MPCB_INT_RK4: the reference's NLP and plant are explicit Euler (kin.py:207); no RK4 mode is built");
   if (c->integrator != MPCB_INT_EULER) return fail(h, MPCB_E_INVALID, "unknown integrator %d", c->integrator);
   if (c->restoration != 0 && c->restoration != 1) return fail(h, MPCB_E_INVALID, "restoration must be 0 or 1");
+  if (c->second_start != 0 && c->second_start != 1) return fail(h, MPCB_E_INVALID, "second_start must be 0 or 1");
   if (std::isfinite(c->x_lo[0]) || std::isfinite(c->x_hi[0]) || std::isfinite(c->x_lo[2]) || std::isfinite(c->x_hi[2]))
     return fail(h, MPCB_E_UNSUPPORTED, "state boxes are supported on y, vx (and vy for the dynamic model) (kin.py:97-105, dyn.py:97-110)");
   if (c->model == MPCB_MODEL_KIN) {
@@ -439,7 +444,8 @@ int ensure_lanes(mpcb_handle* h, int k) {
   return MPCB_OK;
 }
 
-bool two_pass(const mpcb_config& c) { return c.restoration != 0; }
+bool second_pass(const mpcb_config& c) { return c.second_start != 0 && c.init_rollout != 0; }      // a second start exists only after a roll-out start
+bool multi_pass(const mpcb_config& c) { return c.restoration != 0 || second_pass(c); }
 
 // both passes of one solve on lane `lane_id` (0 = the handle's own stream)
 int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in, int lane_id = 0) {
@@ -454,8 +460,8 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in, int lane_id = 0) {
     HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
     HIP_TRY(h, hipStreamWaitEvent(stream, h->ev_fork, 0));
   }
-  a.pass = 0; a.work = nullptr;
-  if (two_pass(h->cfg)) {
+  a.pass = MPCB_PASS_FIRST; a.work = nullptr;
+  if (multi_pass(h->cfg)) {
     if (a.B > L.work_cap) {       // grows with the largest batch seen (first call of a given size only)
       HIP_TRY(h, hipStreamSynchronize(stream));
       if (L.d_work) HIP_TRY(h, hipFree(L.d_work));
@@ -480,25 +486,28 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in, int lane_id = 0) {
   HIP_TRY(h, hipEventRecord(evp.first, stream));
   const int n = h->cfg.n_obs;
   int rc = MPCB_OK;
-  if (h->cfg.model == MPCB_MODEL_DYN) {
-    if (n <= 1) rc = launch_kernel(h, stream, mpcb_kernel_dyn<1>, a, lds);
-    else if (n <= 3) rc = launch_kernel(h, stream, mpcb_kernel_dyn<3>, a, lds);
-    else if (n <= 5) rc = launch_kernel(h, stream, mpcb_kernel_dyn<5>, a, lds);
-    else rc = launch_kernel(h, stream, mpcb_kernel_dyn<8>, a, lds);
-  } else if (h->cfg.obs_mode == MPCB_OBS_DCBF && h->cfg.gamma < 1.0 - 1e-12 && n > 0) {   // general-gamma CBF rows
-    if (n == 1) rc = launch_kernel(h, stream, mpcb_kernel_kin<1, true>, a, lds);
-    else if (n <= 3) rc = launch_kernel(h, stream, mpcb_kernel_kin<3, true>, a, lds);
-    else rc = launch_kernel(h, stream, mpcb_kernel_kin<8, true>, a, lds);
-  } else if (n == 0) rc = launch_kernel(h, stream, mpcb_kernel_kin<0>, a, lds);
-  else if (n == 1) rc = launch_kernel(h, stream, mpcb_kernel_kin<1>, a, lds);
-  else if (n <= 3) rc = launch_kernel(h, stream, mpcb_kernel_kin<3>, a, lds);
-  else if (n <= 5) rc = launch_kernel(h, stream, mpcb_kernel_kin<5>, a, lds);
-  else rc = launch_kernel(h, stream, mpcb_kernel_kin<8>, a, lds);
-  if (rc != MPCB_OK) return rc;
-  HIP_TRY(h, hipGetLastError());
-  if (two_pass(h->cfg)) {
-    // restoration pass over the same grid: instances that ended the first pass with MPCB_ST_NEEDS_RESTO continue, the others return
-    a.pass = 1;
+  auto lean_pass = [&](int pass) -> int {         // the lean main-phase kernel over the whole grid
+    a.pass = pass;
+    if (h->cfg.model == MPCB_MODEL_DYN) {
+      if (n <= 1) rc = launch_kernel(h, stream, mpcb_kernel_dyn<1>, a, lds);
+      else if (n <= 3) rc = launch_kernel(h, stream, mpcb_kernel_dyn<3>, a, lds);
+      else if (n <= 5) rc = launch_kernel(h, stream, mpcb_kernel_dyn<5>, a, lds);
+      else rc = launch_kernel(h, stream, mpcb_kernel_dyn<8>, a, lds);
+    } else if (h->cfg.obs_mode == MPCB_OBS_DCBF && h->cfg.gamma < 1.0 - 1e-12 && n > 0) {   // general-gamma CBF rows
+      if (n == 1) rc = launch_kernel(h, stream, mpcb_kernel_kin<1, true>, a, lds);
+      else if (n <= 3) rc = launch_kernel(h, stream, mpcb_kernel_kin<3, true>, a, lds);
+      else rc = launch_kernel(h, stream, mpcb_kernel_kin<8, true>, a, lds);
+    } else if (n == 0) rc = launch_kernel(h, stream, mpcb_kernel_kin<0>, a, lds);
+    else if (n == 1) rc = launch_kernel(h, stream, mpcb_kernel_kin<1>, a, lds);
+    else if (n <= 3) rc = launch_kernel(h, stream, mpcb_kernel_kin<3>, a, lds);
+    else if (n <= 5) rc = launch_kernel(h, stream, mpcb_kernel_kin<5>, a, lds);
+    else rc = launch_kernel(h, stream, mpcb_kernel_kin<8>, a, lds);
+    if (rc != MPCB_OK) return rc;
+    HIP_TRY(h, hipGetLastError());
+    return MPCB_OK;
+  };
+  auto resto_pass = [&]() -> int {                // the restoration-pass kernel: instances that ended the pass before it with MPCB_ST_NEEDS_RESTO continue, the others return
+    a.pass = MPCB_PASS_RESTO;
     const bool dyn = h->cfg.model == MPCB_MODEL_DYN;
     const size_t lds2 = (size_t)(dyn ? mpcbk::layout_dyn(h->cfg.N, true, mpcbk::obs_in_lds(mpcbk::obs_capacity_dyn(n))).total
                                      : mpcbk::layout_kin(h->cfg.N, h->nz, true, mpcbk::obs_in_lds(mpcbk::obs_capacity_kin(n, is_gen(h->cfg))), is_gen(h->cfg)).total) * sizeof(double);
@@ -520,7 +529,18 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in, int lane_id = 0) {
     else rc = launch_kernel(h, stream, mpcb_kernel_kin_resto<8>, a, lds2);
     if (rc != MPCB_OK) return rc;
     HIP_TRY(h, hipGetLastError());
+    return MPCB_OK;
+  };
+  // first attempt from the caller's start, its restoration pass; with a second start (cfg.second_start after a roll-out start) the
+  // lean kernel once more over the same grid, where only the instances whose first attempt did not succeed run from z = 0, and the
+  // restoration pass of that attempt
+  rc = lean_pass(MPCB_PASS_FIRST);
+  if (rc == MPCB_OK && h->cfg.restoration) rc = resto_pass();
+  if (rc == MPCB_OK && second_pass(h->cfg)) {
+    rc = lean_pass(MPCB_PASS_SECOND);
+    if (rc == MPCB_OK && h->cfg.restoration) rc = resto_pass();
   }
+  if (rc != MPCB_OK) return rc;
   HIP_TRY(h, hipEventRecord(evp.second, stream));
   h->ev_head = (h->ev_head + 1) % mpcb_handle::EV_RING; ++h->ev_pending;
   if (lane_id > 0) { HIP_TRY(h, hipEventRecord(L.done, stream)); L.busy = true; }
@@ -577,7 +597,7 @@ int solve_next_lane(mpcb_handle* h, int32_t B, const double* d_x0, const double*
 
 extern "C" {
 
-const char* mpcb_version(void) { return "mpcbatch 0.2 (gfx950, abi 2)"; }
+const char* mpcb_version(void) { return "mpcbatch 0.3 (gfx950, abi 3)"; }
 
 int mpcb_default_config(mpcb_config* cfg, int32_t model, int32_t N, double T) {
   if (!cfg || (model != MPCB_MODEL_KIN && model != MPCB_MODEL_DYN)) return MPCB_E_INVALID;
@@ -612,6 +632,11 @@ int mpcb_default_config(mpcb_config* cfg, int32_t model, int32_t N, double T) {
   }
   // IPOPT defaults; mu_init is raised from IPOPT's 0.1 because the roll-out start is already dynamics-feasible
   c.tol = 1e-8; c.mu_init = 10.0; c.bound_push = 0.01; c.bound_frac = 0.01; c.bound_relax = 1e-8; c.max_gradient = 100.0;
+  // termination: IPOPT's defaults, and the two options the reference sets (kin.py:252-253)
+  c.dual_inf_tol = 1.0; c.constr_viol_tol = 1e-4; c.compl_inf_tol = 1e-4;
+  c.acceptable_tol = 1e-8; c.acceptable_obj_change_tol = 1e-6; c.acceptable_iter = 15;
+  c.acceptable_constr_viol_tol = 1e-2; c.acceptable_dual_inf_tol = 1e10; c.acceptable_compl_inf_tol = 1e-2;
+  c.second_start = 1;
   *cfg = c;
   return MPCB_OK;
 }

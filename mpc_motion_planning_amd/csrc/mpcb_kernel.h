@@ -33,8 +33,11 @@ struct MpcbKArgs {
   mpcb_config cfg;
   int32_t B, nz, ng, obs_kind, want_mult, trace_instance;
   int32_t st_stride;   // status / iters of instance b go to index b * st_stride (the closed loop writes its [B, steps] histories directly)
-  int32_t pass;        // 0: first pass (main phase; an instance that needs the restoration phase ends with MPCB_ST_NEEDS_RESTO and a
-                       //    hand-over record in `work`); 1: restoration pass (RESTO kernel instantiation, only those instances run)
+  int32_t pass;        // MPCB_PASS_FIRST: main phase from the caller's start; an instance that needs the restoration phase ends with
+                       //   MPCB_ST_NEEDS_RESTO and a hand-over record in `work`;
+                       // MPCB_PASS_RESTO: restoration pass (RESTO kernel instantiation), only the MPCB_ST_NEEDS_RESTO instances run;
+                       // MPCB_PASS_SECOND: the lean kernel once more from the second start (cfg.second_start), only the instances whose first
+                       //   attempt did not succeed run; mpcb_api.hip follows it with another MPCB_PASS_RESTO launch
   const double* tgrid; // [N] step length of every stage (mpcb_set_time_grid), NULL = cfg.T everywhere
   double* work;        // [B][WK_SIZE] hand-over records between the passes (device scratch of the handle), NULL when cfg.restoration == 0
   const double *x0, *xs, *obs, *z0;
@@ -56,8 +59,11 @@ struct MpcbKArgs {
 #define MPCB_SCHED_FENCE() ((void)0)
 #endif
 
-// internal status between the two passes of a solve; never returned to the caller
+// internal statuses between the passes of a solve; never returned to the caller
 #define MPCB_ST_NEEDS_RESTO 7
+#define MPCB_PASS_FIRST 0
+#define MPCB_PASS_SECOND 1
+#define MPCB_PASS_RESTO 2
 
 namespace mpcbk {
 
@@ -72,7 +78,7 @@ constexpr int TRIG_K = 5;
 // solve ends with MPCB_ST_RESTO_FAILED (a launch ends with its slowest instance: the phase must not run to max_iter)
 constexpr int RS_MAX_CALLS = 3, RS_MAX_ITERS = 40;
 // hand-over record of an instance that needs the restoration pass
-constexpr int WK_MU = 0, WK_THMAX = 1, WK_THMIN = 2, WK_ITERS = 3, WK_DW = 4, WK_SIZE = 8;
+constexpr int WK_MU = 0, WK_THMAX = 1, WK_THMIN = 2, WK_ITERS = 3, WK_DW = 4, WK_ITPREV = 5, WK_START = 6, WK_SIZE = 8;   // WK_ITPREV: iterations of the failed first attempt; WK_START: 1 = the attempt handed over started from z = 0
 // per-node cost table of the RESTO instantiations, [row][N+2] in LDS (lane = node, lanes beyond the last node share the dummy column N+1): scaled weights osc*2*Qc, reference point,
 // osc*2*Rc, control reference, the unscaled weights Qc, Rc, and the rate-cost weights osc*2*DRc, DRc
 enum CostRow { CT_WQ = 0, CT_XR = 4, CT_WR = 8, CT_UR = 10, CT_QQ = 12, CT_RR = 16, CT_WDR = 18, CT_DRR = 20, CT_ROWS = 22 };
@@ -100,7 +106,7 @@ constexpr int PST = 50, PS_P = 36, PS_ZERO = 42, PS_PADP = 43, PS_PAD = 44;
 constexpr int FWR = 8, FWS = 50, FW_C0 = 6, FW_BX = 7, FW_PAD = 48, FW_ZERO = 1, FW_ONE = 0, WSZ = 136, W_ZERO = 64, W_STAGE = 72;
 // constant block: uniform numbers of the instance that the node-parallel phases read from LDS (one ds_read, short live range)
 // instead of holding ~25 SGPR pairs through the whole solve
-constexpr int CS_WQ = 0, CS_WR = 4, CS_WDR = 6, CS_Q = 8, CS_R = 12, CS_DR = 14, CS_UL = 16, CS_XS = 18, CSZ = 24;
+constexpr int CS_WQ = 0, CS_WR = 4, CS_WDR = 6, CS_Q = 8, CS_R = 12, CS_DR = 14, CS_UL = 16, CS_XS = 18, CS_ACC = 24, CSZ = 26;   // CS_ACC: state of the acceptable-point test (objective at the previous check, iterations in a row)
 struct Layout {
   int ld, ent, Pst, fw, W, cst, filt, zbuf, ct, obl, total;
 };
@@ -215,6 +221,16 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   const int N = c.N, lane = wv::lane(), k = lane;
   const int nz = a.nz, nobs = c.n_obs;
   if (RESTO && a.status[(size_t)b * a.st_stride] != MPCB_ST_NEEDS_RESTO) return;     // wave-uniform: this instance is done
+  if (!RESTO && a.pass == MPCB_PASS_SECOND) {          // second start: only instances whose first attempt (restoration included) did not succeed
+    const int st1 = a.status[(size_t)b * a.st_stride];
+    if (st1 == MPCB_ST_SOLVED || st1 == MPCB_ST_ACCEPTABLE || st1 == MPCB_ST_INFEASIBLE_X0) return;
+  }
+  // Which start does this solve run from?  First attempt: the caller's z0, with X rolled out from x0 (cfg.init_rollout).  Second
+  // attempt (cfg.second_start, only after a roll-out start; mpcb_api.hip launches its passes after the first attempt's): the
+  // reference's own first-step start z = 0 (main_cbf_kin_c_sim.py:47-50), no roll-out.  A restoration pass continues whichever
+  // attempt handed over (WK_START).
+  const bool zeros_start = RESTO ? (a.work && a.work[(size_t)b * mpcbk::WK_SIZE + mpcbk::WK_START] != 0.0) : a.pass == MPCB_PASS_SECOND;
+  const bool rollout = c.init_rollout && !zeros_start;
   constexpr bool OBL = NOBS > 3;                  // obstacle constants in LDS ([4 * j + q][lane]) instead of registers
   const Layout L = layout_kin(N, nz, RESTO, obs_in_lds(NOBS), GEN);
   const int ld = L.ld;
@@ -271,7 +287,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
 
   // ----- start point: z0 row (coalesced) -> LDS -> node lanes ---------------------------------------------------
   double* zbuf = lds + L.zbuf;
-  for (int i = lane; i < nz; i += 64) zbuf[i] = a.z0 ? a.z0[(size_t)b * nz + i] : 0.0;
+  for (int i = lane; i < nz; i += 64) zbuf[i] = (a.z0 && !zeros_start) ? a.z0[(size_t)b * nz + i] : 0.0;
   wv::sync();
   double X[NX], U[NU], lam[NX];
 #pragma unroll
@@ -318,6 +334,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     for (int i = 0; i < NX; ++i) { cst[CS_WQ + i] = os * 2 * c.Q[i]; cst[CS_Q + i] = c.Q[i]; cst[CS_XS + i] = xs[i]; }
 #pragma unroll
     for (int i = 0; i < NU; ++i) { cst[CS_WR + i] = os * 2 * c.R[i]; cst[CS_WDR + i] = os * 2 * c.DR[i]; cst[CS_R + i] = c.R[i]; cst[CS_DR + i] = c.DR[i]; cst[CS_UL + i] = c.u_last[i]; }
+    cst[CS_ACC] = 1e300; cst[CS_ACC + 1] = 0.0;
   }
   wv::sync();
   // The objective of the running phase.  First-pass instantiation: the uniform constants of the block above.  RESTO instantiation:
@@ -421,7 +438,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   };
 
   // optional roll-out of X from x0 with the guessed (clipped) controls
-  if (!RESTO && c.init_rollout) {
+  if (!RESTO && rollout) {
     U[0] = hasu ? fmin(fmax(U[0], c.u_lo[0]), c.u_hi[0]) : 0.0;
     U[1] = hasu ? fmin(fmax(U[1], c.u_lo[1]), c.u_hi[1]) : 0.0;
     double sd, cd; sincos_b(U[0], sd, cd);
@@ -707,6 +724,8 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         ++n_rcalls;
         // ----- entry into the restoration phase (oracle: Solver::restoration) ------------------------------------------------
         enter = false;
+        if (lane == 0) { cst[CS_ACC] = 1e300; cst[CS_ACC + 1] = 0.0; }      // (the acceptable-point counter starts afresh after a restoration, in both passes alike)
+        wv::sync();
         mu_main = mu; tmax_main = theta_max; tmin_main = theta_min;
         rs = false; osc = os;
         // slacks of the general rows re-initialised from w as at a fresh start; the entry pair of the main filter is taken there
@@ -843,7 +862,21 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           t[0] = mu; t[1] = err0; t[2] = theta; t[3] = fval;
         }
         if (!(RESTO && rs)) {
-          if (err0 <= c.tol) { status = MPCB_ST_SOLVED; break; }
+          // IPOPT's OptimalityErrorConvergenceCheck: "optimal" = scaled error AND the three unscaled gates (dual infeasibility and
+          // complementarity of the scaled problem divided by the objective scaling; there is no constraint scaling); then the
+          // acceptable-point counter with the reference's two options (kin.py:252-253)
+          const double compl0 = n_vr > 0 ? sv_hi : 0.0;
+          const auto* lc = &wv::late_args(a)->cfg;       // the nine tolerances are loaded here, once per iteration, and are dead again after the test
+          if (err0 <= lc->tol && e_dual <= lc->dual_inf_tol * os && e_prim <= lc->constr_viol_tol && compl0 <= lc->compl_inf_tol * os) { status = MPCB_ST_SOLVED; break; }
+          const double fcur = os * fval;
+          const bool acc = lc->acceptable_iter > 0 && err0 <= lc->acceptable_tol && e_dual <= lc->acceptable_dual_inf_tol * os &&
+                           e_prim <= lc->acceptable_constr_viol_tol && compl0 <= lc->acceptable_compl_inf_tol * os &&
+                           fabs(fcur - cst[CS_ACC]) <= lc->acceptable_obj_change_tol * fmax(1.0, fabs(fcur));
+          const double acc_cnt = acc ? cst[CS_ACC + 1] + 1.0 : 0.0;
+          wv::sync();
+          if (lane == 0) { cst[CS_ACC] = fcur; cst[CS_ACC + 1] = acc_cnt; }
+          wv::sync();
+          if (acc && acc_cnt >= (double)lc->acceptable_iter) { status = MPCB_ST_ACCEPTABLE; break; }
           if (iters >= c.max_iter) { status = MPCB_ST_MAXITER; break; }
         } else {
           // ----- restoration phase: has it done its job?  Violation of the ORIGINAL rows and the original barrier function here
@@ -1346,6 +1379,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         if (lane == 0 && a.work) {
           double* wk = a.work + (size_t)b * WK_SIZE;
           wk[WK_MU] = mu; wk[WK_THMAX] = theta_max; wk[WK_THMIN] = theta_min; wk[WK_ITERS] = (double)it_done; wk[WK_DW] = dw_last;
+          wk[WK_START] = a.pass == MPCB_PASS_SECOND ? 1.0 : 0.0;
         }
       };
       if (!accepted) {
@@ -1410,7 +1444,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       ++iters;
       if (RESTO && rs) { ++rit; ++n_riters; }
       else if (c.restoration) {
-        // early entry into restoration: TRIG_K accepted steps in a row shorter than TRIG_ALPHA that together reduced theta by less
+        // early entry into restoration (or hand-over to the second start): TRIG_K accepted steps in a row shorter than TRIG_ALPHA that together reduced theta by less
         // than the factor TRIG_THETA (a slack pinned at its bound with the row still violated: the pattern of an infeasible
         // instance; IPOPT itself waits for the line search to fail, dozens of such steps later)
         if (alpha < TRIG_ALPHA && theta > 1e-6) { if (slow_run == 0) slow_theta0 = th0; ++slow_run; } else slow_run = 0;
@@ -1451,7 +1485,16 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   if (lo == 0) {
     if (a.obj) a.obj[b] = fval;
     if (a.status) a.status[(size_t)b * a.st_stride] = status;
-    if (a.iters) a.iters[(size_t)b * a.st_stride] = iters;
+    // iterations of both attempts are counted (cfg.second_start): the first attempt leaves its total in the hand-over record, the
+    // passes of the second attempt add it (read here, not kept live through the solve)
+    int it_prev = 0;
+    if (a.work) {
+      double* wk = a.work + (size_t)b * mpcbk::WK_SIZE;
+      const bool second_attempt = RESTO ? wk[mpcbk::WK_START] != 0.0 : a.pass == MPCB_PASS_SECOND;
+      if (second_attempt) it_prev = (int)wk[mpcbk::WK_ITPREV];
+      else if (status != MPCB_ST_NEEDS_RESTO) wk[mpcbk::WK_ITPREV] = (double)iters;
+    }
+    if (a.iters) a.iters[(size_t)b * a.st_stride] = iters + it_prev;
     if (a.kkt) { double* q = a.kkt + (size_t)b * 4; q[0] = err0; q[1] = e_prim; q[2] = e_dual / os; q[3] = mu; }
   }
   if (a.want_mult && a.lam_x) {

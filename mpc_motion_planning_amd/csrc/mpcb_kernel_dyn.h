@@ -33,7 +33,7 @@ enum DynEnt {
 //                   single copy keeps the N = 40 instance at 53 KB, three workgroups per CU instead of two
 constexpr int DPST = 66 /* P_k 8x8 + 2 pad slots for the stores of the lanes below the diagonal */, DPSS = 10, DFWS = 46, DFW_KFF = 16, DFW_A = 18, DFW_B = 32, DFW_D = 34, DFW_PAD = 40, DFW_ONE = 42, DFW_ZERO = 43, DFW_T = 44, DWSZ = 64, DWU = 16 + 16;
 // constant block (as in the kin kernel): cost weights, reference state and last control, read from LDS by the node-parallel phases
-constexpr int DCS_WQ = 0, DCS_WR = 6, DCS_WDR = 8, DCS_Q = 10, DCS_R = 16, DCS_DR = 18, DCS_UL = 20, DCS_XS = 22, DCSZ = 28;
+constexpr int DCS_WQ = 0, DCS_WR = 6, DCS_WDR = 8, DCS_Q = 10, DCS_R = 16, DCS_DR = 18, DCS_UL = 20, DCS_XS = 22, DCS_ACC = 28, DCSZ = 30;   // DCS_ACC: state of the acceptable-point test (objective at the previous check, iterations in a row)
 // per-node cost table of the RESTO instantiation, [row][N+2] (see CostRow in mpcb_kernel.h)
 enum DynCostRow { DCT_WQ = 0, DCT_XR = 6, DCT_WR = 12, DCT_UR = 14, DCT_QQ = 16, DCT_RR = 22, DCT_WDR = 24, DCT_DRR = 26, DCT_ROWS = 28 };
 struct LayoutDyn { int ld, ent, Pst, pst, fw, W, Wu, cst, filt, zbuf, ct, obl, total; };
@@ -138,9 +138,22 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   using namespace mpcbk;
   constexpr int NX = 6, NA = 8, NW = 10, NOB = NOBS > 0 ? NOBS : 1, NEL = RESTO ? NOB : 1;
   const mpcb_config& c = a.cfg;
+  // the eight vehicle / tyre constants of the model are loaded from the kernel arguments at every model evaluation instead of living in
+  // 16+ scalar registers for the whole solve (wv::late_args): the dyn kernels spill SGPRs into VGPR lanes by the hundred
+  auto MC = [&]() -> const mpcb_config& { return wv::late_args(a)->cfg; };
   const int N = c.N, lane = wv::lane(), k = lane;
   const int nz = a.nz, nobs = c.n_obs;
   if (RESTO && a.status[(size_t)b * a.st_stride] != MPCB_ST_NEEDS_RESTO) return;     // wave-uniform: this instance is done
+  if (!RESTO && a.pass == MPCB_PASS_SECOND) {          // second start: only instances whose first attempt (restoration included) did not succeed
+    const int st1 = a.status[(size_t)b * a.st_stride];
+    if (st1 == MPCB_ST_SOLVED || st1 == MPCB_ST_ACCEPTABLE || st1 == MPCB_ST_INFEASIBLE_X0) return;
+  }
+  // Which start does this solve run from?  First attempt: the caller's z0, with X rolled out from x0 (cfg.init_rollout).  Second
+  // attempt (cfg.second_start, only after a roll-out start; mpcb_api.hip launches its passes after the first attempt's): the
+  // reference's own first-step start z = 0 (main_cbf_kin_c_sim.py:47-50), no roll-out.  A restoration pass continues whichever
+  // attempt handed over (WK_START).
+  const bool zeros_start = RESTO ? (a.work && a.work[(size_t)b * mpcbk::WK_SIZE + mpcbk::WK_START] != 0.0) : a.pass == MPCB_PASS_SECOND;
+  const bool rollout = c.init_rollout && !zeros_start;
   constexpr bool OBL = NOBS > 3;                  // obstacle constants in LDS instead of registers (see mpcb_solve_kin)
   const LayoutDyn L = layout_dyn(N, RESTO, obs_in_lds(NOBS));
   const int ld = L.ld;
@@ -187,13 +200,14 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   };
 
   double* zbuf = lds + L.zbuf;
-  for (int i = lane; i < nz; i += 64) zbuf[i] = a.z0 ? a.z0[(size_t)b * nz + i] : 0.0;
+  for (int i = lane; i < nz; i += 64) zbuf[i] = (a.z0 && !zeros_start) ? a.z0[(size_t)b * nz + i] : 0.0;
   wv::sync();
   double X[NX], U[NU], lam[NX];
 #pragma unroll
   for (int i = 0; i < NU; ++i) U[i] = hasu ? zbuf[NU * k + i] : 0.0;
 #pragma unroll
   for (int i = 0; i < NX; ++i) { X[i] = isnode ? zbuf[NU * N + NX * k + i] : 0.0; lam[i] = 0.0; }
+  if (zeros_start && isnode) X[3] = gx0[3];       // second start: z = 0 except the longitudinal speed (the tyre model divides by vx, dyn.py:156-157)
   wv::sync();
 
   double os;
@@ -233,6 +247,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
     for (int i = 0; i < NX; ++i) { cst[DCS_WQ + i] = os * 2 * c.Q[i]; cst[DCS_Q + i] = c.Q[i]; cst[DCS_XS + i] = xs[i]; }
 #pragma unroll
     for (int i = 0; i < NU; ++i) { cst[DCS_WR + i] = os * 2 * c.R[i]; cst[DCS_WDR + i] = os * 2 * c.DR[i]; cst[DCS_R + i] = c.R[i]; cst[DCS_DR + i] = c.DR[i]; cst[DCS_UL + i] = c.u_last[i]; }
+    cst[DCS_ACC] = 1e300; cst[DCS_ACC + 1] = 0.0;
   }
   wv::sync();
   // objective of the running phase: uniform constants (first pass) or the per-node table of the RESTO instantiation
@@ -317,7 +332,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   const bool ro_node = xnode && obs_node;
   const bool ducost = hasu && (k > 0 || c.du0_cost);     // (U_k - U_{k-1})' DR (.) present in stage k     dyn.py:221-224
 
-  if (!RESTO && c.init_rollout) {
+  if (!RESTO && rollout) {
     U[0] = hasu ? fmin(fmax(U[0], c.u_lo[0]), c.u_hi[0]) : 0.0;
     U[1] = hasu ? fmin(fmax(U[1], c.u_lo[1]), c.u_hi[1]) : 0.0;
 #pragma clang loop unroll(disable)
@@ -326,8 +341,8 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) Xs[i] = X[i];
       if (!okx) Xs[3] = 1e-3;
-      DynEval e; dyn_eval(c, Xs, U, e);
-      double F[NX]; dyn_F(c, T, Xs, U, e, F);
+      DynEval e; dyn_eval(MC(), Xs, U, e);
+      double F[NX]; dyn_F(MC(), T, Xs, U, e, F);
 #pragma unroll
       for (int i = 0; i < NX; ++i) { const double n = wv::bcast(F[i], s); if (k == s + 1) X[i] = n; }
     }
@@ -375,7 +390,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   auto eval_lane = [&](const double* Xa, const double* Ua, double sR0a, double sR1a, const double* sOa, const double* pa, const double* na, const DynEval& e,
                        double* dfa, double& rR0a, double& rR1a, double* rOa, double& up0, double& up1, double& th, double& fl, double& prod) {
     bool ok = true;
-    double Ft[NX]; dyn_F(c, T, Xa, Ua, e, Ft);
+    double Ft[NX]; dyn_F(MC(), T, Xa, Ua, e, Ft);
     th = 0; fl = 0; prod = 1.0;
 #pragma unroll
     for (int i = 0; i < NX; ++i) { const double xn = wv::shfl(Xa[i], k + 1); dfa[i] = hasu ? Ft[i] - xn : 0.0; th += fabs(dfa[i]); }
@@ -522,7 +537,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
 #pragma unroll
     for (int j = 0; j < NOBS; ++j) if (ro_on[j]) { gO0[j] = 2 * (X[0] - ox(j)) * ix2(j); gO1[j] = 2 * (X[1] - oy(j)) * iy2(j); }
     if (!RESTO) {
-      DynEval ev; dyn_eval(c, X, U, ev);
+      DynEval ev; dyn_eval(MC(), X, U, ev);
       double th, fl, prod;
       eval_lane(X, U, sR0, sR1, sO, eP, eN, ev, dfc, rR0, rR1, rO, Up0, Up1, th, fl, prod);
       double sv[3] = {th, fl, log(prod)};
@@ -547,9 +562,11 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         ++n_rcalls;
         // ----- entry into the restoration phase (oracle: Solver::restoration; comments in mpcb_solve_kin) ----------------------
         enter = false;
+        if (lane == 0) { cst[DCS_ACC] = 1e300; cst[DCS_ACC + 1] = 0.0; }      // (the acceptable-point counter starts afresh after a restoration, in both passes alike)
+        wv::sync();
         mu_main = mu; tmax_main = theta_max; tmin_main = theta_min;
         rs = false; osc = os;
-        DynEval ev; dyn_eval(c, X, U, ev);
+        DynEval ev; dyn_eval(MC(), X, U, ev);
         Up0 = wv::shfl(U[0], k - 1); Up1 = wv::shfl(U[1], k - 1);
         if (r0_on) sR0 = push_in(qR0, U[0] - Up0, c.bound_push, c.bound_frac);
         if (r1_on) sR1 = push_in(qR1, U[1] - Up1, c.bound_push, c.bound_frac);
@@ -604,8 +621,8 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       }
       MPCB_STAMP(t_a);
       // tyre forces and trig at the iterate are recomputed here rather than kept across the line search (13 doubles/lane)
-      DynEval ev; dyn_eval(c, X, U, ev);
-      DynJac J; dyn_jac(c, T, X, ev, J);
+      DynEval ev; dyn_eval(MC(), X, U, ev);
+      DynJac J; dyn_jac(MC(), T, X, ev, J);
       recips();
       double ln[NX];
 #pragma unroll
@@ -688,7 +705,21 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
           t[0] = mu; t[1] = err0; t[2] = theta; t[3] = fval;
         }
         if (!(RESTO && rs)) {
-          if (err0 <= c.tol) { status = MPCB_ST_SOLVED; break; }
+          // IPOPT's OptimalityErrorConvergenceCheck: "optimal" = scaled error AND the three unscaled gates (dual infeasibility and
+          // complementarity of the scaled problem divided by the objective scaling; there is no constraint scaling); then the
+          // acceptable-point counter with the reference's two options (kin.py:252-253)
+          const double compl0 = n_vr > 0 ? sv_hi : 0.0;
+          const auto* lc = &wv::late_args(a)->cfg;       // the nine tolerances are loaded here, once per iteration, and are dead again after the test
+          if (err0 <= lc->tol && e_dual <= lc->dual_inf_tol * os && e_prim <= lc->constr_viol_tol && compl0 <= lc->compl_inf_tol * os) { status = MPCB_ST_SOLVED; break; }
+          const double fcur = os * fval;
+          const bool acc = lc->acceptable_iter > 0 && err0 <= lc->acceptable_tol && e_dual <= lc->acceptable_dual_inf_tol * os &&
+                           e_prim <= lc->acceptable_constr_viol_tol && compl0 <= lc->acceptable_compl_inf_tol * os &&
+                           fabs(fcur - cst[DCS_ACC]) <= lc->acceptable_obj_change_tol * fmax(1.0, fabs(fcur));
+          const double acc_cnt = acc ? cst[DCS_ACC + 1] + 1.0 : 0.0;
+          wv::sync();
+          if (lane == 0) { cst[DCS_ACC] = fcur; cst[DCS_ACC + 1] = acc_cnt; }
+          wv::sync();
+          if (acc && acc_cnt >= (double)lc->acceptable_iter) { status = MPCB_ST_ACCEPTABLE; break; }
           if (iters >= c.max_iter) { status = MPCB_ST_MAXITER; break; }
         } else {
           // ----- restoration phase: violation of the ORIGINAL rows and the original barrier function at this iterate
@@ -816,7 +847,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
             hd[8] += w0; hd[6] += w0; h68 -= w0; hd[9] += w1; hd[7] += w1; h79 -= w1;
             g[8] += w0 * d0; g[6] -= w0 * d0; g[9] += w1 * d1; g[7] -= w1 * d1;
           }
-          dyn_hess(c, T, X, ev, ln, Hh);
+          dyn_hess(MC(), T, X, ev, ln, Hh);
           hd[2] += Hh.h22; hd[3] += Hh.h33; hd[4] += Hh.h44; hd[5] += Hh.h55; hd[8] += Hh.h88;
         }
         double sig, gb;
@@ -1107,7 +1138,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
 #pragma unroll
           for (int j = 0; j < NOBS; ++j) { pt[j] = eP[j] + alpha * dP[j]; nt[j] = eN[j] + alpha * dN[j]; }
         }
-        dyn_eval(c, Xt, Ut, et);
+        dyn_eval(MC(), Xt, Ut, et);
         double th, fl, prod;
         const bool okl = eval_lane(Xt, Ut, sR0t, sR1t, sOt, pt, nt, et, dft, rR0t, rR1t, rOt, upt0, upt1, th, fl, prod);
         double sv[4] = {th, fl, okl ? log(prod) : 0.0, okl ? 0.0 : 1.0};
@@ -1146,6 +1177,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         if (lane == 0 && a.work) {
           double* wk = a.work + (size_t)b * WK_SIZE;
           wk[WK_MU] = mu; wk[WK_THMAX] = theta_max; wk[WK_THMIN] = theta_min; wk[WK_ITERS] = (double)it_done; wk[WK_DW] = dw_last;
+          wk[WK_START] = a.pass == MPCB_PASS_SECOND ? 1.0 : 0.0;
         }
       };
       if (!accepted) {
@@ -1212,7 +1244,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
       if (!isfinite(theta) || !isfinite(fval)) { status = MPCB_ST_NUMERIC; break; }
       ++iters;
       if (RESTO && rs) { ++rit; ++n_riters; }
-      else if (c.restoration) {       // early entry into restoration (see mpcb_solve_kin)
+      else if (c.restoration) {       // early entry into restoration / hand-over to the second start (see mpcb_solve_kin)
         if (alpha < TRIG_ALPHA && theta > 1e-6) { if (slow_run == 0) slow_theta0 = th0; ++slow_run; } else slow_run = 0;
         if (slow_run >= TRIG_K && theta > TRIG_THETA * slow_theta0) {
           slow_run = 0;
@@ -1226,14 +1258,14 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) Xs[i] = X[i];
     if (!(Xs[3] > 1e-3)) Xs[3] = 1e-3;
-    DynEval ev; dyn_eval(c, Xs, U, ev);
+    DynEval ev; dyn_eval(MC(), Xs, U, ev);
     double th, fl, prod;
     eval_lane(Xs, U, sR0, sR1, sO, eP, eN, ev, dfc, rR0, rR1, rO, Up0, Up1, th, fl, prod);
     fval = wv::sum(fl);
   }
   if (RESTO && rs) {    // ended inside the restoration phase: report the objective of the original problem
     rs = false; osc = os; write_main_cost();
-    DynEval ev; dyn_eval(c, X, U, ev);
+    DynEval ev; dyn_eval(MC(), X, U, ev);
     double th, fl, prod;
     eval_lane(X, U, sR0, sR1, sO, eP, eN, ev, dfc, rR0, rR1, rO, Up0, Up1, th, fl, prod);
     fval = wv::sum(fl);
@@ -1256,7 +1288,16 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   if (lo == 0) {
     if (a.obj) a.obj[b] = fval;
     if (a.status) a.status[(size_t)b * a.st_stride] = status;
-    if (a.iters) a.iters[(size_t)b * a.st_stride] = iters;
+    // iterations of both attempts are counted (cfg.second_start): the first attempt leaves its total in the hand-over record, the
+    // passes of the second attempt add it (read here, not kept live through the solve)
+    int it_prev = 0;
+    if (a.work) {
+      double* wk = a.work + (size_t)b * mpcbk::WK_SIZE;
+      const bool second_attempt = RESTO ? wk[mpcbk::WK_START] != 0.0 : a.pass == MPCB_PASS_SECOND;
+      if (second_attempt) it_prev = (int)wk[mpcbk::WK_ITPREV];
+      else if (status != MPCB_ST_NEEDS_RESTO) wk[mpcbk::WK_ITPREV] = (double)iters;
+    }
+    if (a.iters) a.iters[(size_t)b * a.st_stride] = iters + it_prev;
     if (a.kkt) { double* q = a.kkt + (size_t)b * 4; q[0] = err0; q[1] = e_prim; q[2] = e_dual / os; q[3] = mu; }
   }
   if (a.want_mult && a.lam_x) {
@@ -1291,8 +1332,8 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) Xs[i] = X[i];
       if (!(Xs[3] > 1e-3)) Xs[3] = 1e-3;
-      DynEval ev; dyn_eval(c, Xs, U, ev);
-      DynJac J; dyn_jac(c, T, Xs, ev, J);
+      DynEval ev; dyn_eval(MC(), Xs, U, ev);
+      DynJac J; dyn_jac(MC(), T, Xs, ev, J);
       const double At[NX] = {ln[0], ln[1], J.a02 * ln[0] + J.a12 * ln[1] + ln[2],
                              J.a03 * ln[0] + J.a13 * ln[1] + ln[3] + J.a43 * ln[4] + J.a53 * ln[5],
                              J.a04 * ln[0] + J.a14 * ln[1] + J.a34 * ln[3] + J.a44 * ln[4] + J.a54 * ln[5],

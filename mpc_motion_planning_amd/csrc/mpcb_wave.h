@@ -94,6 +94,14 @@ template <int NS, int NM> MPCB_DEV void reduce(double* s, double* m) {
 }
 // the same value, but opaque to the optimiser (breaks common-subexpression reuse across the kernel)
 MPCB_DEV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// The kernel's own argument block, re-addressed behind an optimisation barrier: fields read through this pointer are loaded (s_load)
+// where they are used, each time, instead of at kernel entry — for values needed once per iteration (the termination tolerances)
+// that keeps their SGPRs out of the register pressure of the whole solve.  Every solve kernel takes ONE argument, a MpcbKArgs by value.
+template <class T> MPCB_DEV const T* late_args(const T&) {
+  unsigned long long p = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return (const T*)(const __attribute__((address_space(4))) T*)p;      // constant address space: scalar loads
+}
 // a wave-uniform double moved to scalar registers
 MPCB_DEV double uni(double v) {
   int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
@@ -156,6 +164,7 @@ template <int NS, int NM> inline void reduce(double* s, double* m) {
   for (int i = 0; i < NM; ++i) m[i] = max(m[i]);
 }
 inline int opaque(int v) { return v; }
+template <class T> inline const T* late_args(const T& a) { return &a; }
 inline double uni(double v) { return v; }
 inline double rcp(double x) { return 1.0 / x; }
 }  // namespace wv

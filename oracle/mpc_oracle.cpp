@@ -377,7 +377,11 @@ struct Solver {
 
   // ----- problem set-up ----------------------------------------------------------------------------------
   // obstacles: static [nobs][6] or predicted [nobs][N+1][6]; rows [x,y,theta,v,l,w]
-  bool init(const double* x0_, const double* xs_, const double* ob, int obs_kind, const double* z0, const double* tgrid) {
+  // zeros_start: the second attempt of cfg.second_start (only after a roll-out start) — z = 0 whatever z0 says (the reference's own
+  // first-step start, main_cbf_kin_c_sim.py:47-50; dynamic model: 0 except vx = x0's, the tyre model divides by vx), no roll-out
+  bool init(const double* x0_, const double* xs_, const double* ob, int obs_kind, const double* z0, const double* tgrid, bool zeros_start = false) {
+    const bool rollout = c.init_rollout && !zeros_start;
+    if (zeros_start) z0 = nullptr;
     x0 = x0_; xs = xs_;
     for (int k = 0; k < NODES; ++k) Tk[k] = tgrid ? tgrid[k < N ? k : N - 1] : c.T;
     const int last_row = c.obs_terminal ? N : N - 1;       // reference row index range 0..last_row
@@ -398,6 +402,7 @@ struct Solver {
     // iterate from z0 (reference order, kin.py:250), X_0 pinned
     for (int k = 0; k < N; ++k) for (int i = 0; i < NU; ++i) U[k][i] = z0 ? z0[NU * k + i] : 0.0;
     for (int k = 0; k <= N; ++k) for (int i = 0; i < nx; ++i) X[k][i] = z0 ? z0[NU * N + nx * k + i] : 0.0;
+    if (zeros_start && c.model == MPCB_MODEL_DYN) for (int k = 0; k <= N; ++k) X[k][3] = x0[3];
     double X0guess[NXM]; for (int i = 0; i < nx; ++i) X0guess[i] = X[0][i];
     for (int i = 0; i < nx; ++i) X[0][i] = x0[i];
     for (int i = 0; i < NU; ++i) U[N][i] = 0.0;
@@ -421,7 +426,7 @@ struct Solver {
     }
 
     // optional roll-out of X from x0 with the guessed (clipped) controls
-    if (c.init_rollout) {
+    if (rollout) {
       for (int k = 0; k < N; ++k) {
         double Uc[NU]; for (int i = 0; i < NU; ++i) Uc[i] = std::min(std::max(U[k][i], c.u_lo[i]), c.u_hi[i]);
         double f[NXM]; rhs_any(c, X[k], Uc, f);
@@ -957,6 +962,8 @@ struct Solver {
   }
   double last_alpha = 0, last_apr = 0, slow_theta0 = 0;
   int slow_run = 0, trips = 0;
+  int acc_cnt = 0; double f_last = 1e300;       // acceptable-point counter and the objective of the previous convergence check
+  int iters_prev = 0;                           // iterations of the failed first attempt (reported in the sum)
 
   // violation of the ORIGINAL constraints at the iterate: shooting defects and  c(w) - s  of the general rows (l1 and max norm)
   void original_violation(double& th1, double& thinf) {
@@ -983,6 +990,7 @@ struct Solver {
   int restoration() {
     if (n_resto_calls >= o.resto_max_calls) return MPCB_ST_RESTO_FAILED;     // the phase has been tried often enough on this instance
     ++n_resto_calls;
+    acc_cnt = 0; f_last = 1e300;           // the acceptable-point counter starts afresh after a restoration (the HIP kernel's second pass knows nothing of the first's)
     const double mu_main = mu;
     // Entry.  The slacks of the general rows (rate, obstacle) are auxiliary variables; after a stalled main phase they lag behind
     // the row values or sit pinned at a bound.  They are re-initialised from w exactly as at a fresh start (row value pushed
@@ -1093,7 +1101,19 @@ struct Solver {
       if (++trips > 3 * c.max_iter + 50) { status = MPCB_ST_RESTO_FAILED; break; }   // phase changes are not iterations: bound them too
       Err e0 = kkt_error(0.0);
       err0 = Emu(e0);
-      if (err0 <= c.tol) { status = MPCB_ST_SOLVED; break; }
+      // IPOPT's OptimalityErrorConvergenceCheck (IpOptErrorConvCheck.cpp): "optimal" = scaled error <= tol AND the unscaled gates
+      // dual_inf_tol / constr_viol_tol / compl_inf_tol (dual infeasibility and complementarity of the scaled problem divided by the
+      // objective scaling; no constraint scaling here); then the acceptable-point counter: acceptable_iter iterations in a row
+      // within the acceptable_* tolerances whose (scaled) objective changed by <= acceptable_obj_change_tol relative
+      if (err0 <= c.tol && e0.dual <= c.dual_inf_tol * os && e0.prim <= c.constr_viol_tol && e0.comp <= c.compl_inf_tol * os) { status = MPCB_ST_SOLVED; break; }
+      {
+        const double fcur = os * fval;
+        const bool acc = c.acceptable_iter > 0 && err0 <= c.acceptable_tol && e0.dual <= c.acceptable_dual_inf_tol * os &&
+                         e0.prim <= c.acceptable_constr_viol_tol && e0.comp <= c.acceptable_compl_inf_tol * os &&
+                         std::fabs(fcur - f_last) <= c.acceptable_obj_change_tol * std::max(1.0, std::fabs(fcur));
+        f_last = fcur; acc_cnt = acc ? acc_cnt + 1 : 0;
+        if (acc && acc_cnt >= c.acceptable_iter) { status = MPCB_ST_ACCEPTABLE; break; }
+      }
       if (iters >= c.max_iter) { status = MPCB_ST_MAXITER; break; }
       int why = MPCB_ST_LINESEARCH;
       const double th_before = theta;
@@ -1127,7 +1147,7 @@ struct Solver {
     if (obj) { set_main_cost(); *obj = objective(X, U); }
     if (st) *st = status;
     if (std::getenv("MPCO_STATS")) std::fprintf(stderr, "STATS %d %d %d %d %d %d\n", status, iters, n_factor, n_trial, n_resto_calls, n_resto_iters);
-    if (it) *it = iters;
+    if (it) *it = iters + iters_prev;
     if (kkt) {
       double du = 0; Err e = kkt_error(0.0, &du);
       kkt[0] = Emu(e); kkt[1] = e.prim; kkt[2] = du; kkt[3] = mu;
@@ -1225,6 +1245,10 @@ int mpco_default_config(mpcb_config* cfg, int32_t model, int32_t N, double T) {
     c.obs_terminal = 1; c.obs_hmin = 1.0; c.obs_sx_fixed = 4.0; c.obs_sy_fixed = 1.0; c.rate_interleaved = 1;
   }
   c.tol = 1e-8; c.mu_init = 0.1; c.bound_push = 0.01; c.bound_frac = 0.01; c.bound_relax = 1e-8; c.max_gradient = 100.0;
+  c.dual_inf_tol = 1.0; c.constr_viol_tol = 1e-4; c.compl_inf_tol = 1e-4;                       // IPOPT defaults
+  c.acceptable_tol = 1e-8; c.acceptable_obj_change_tol = 1e-6; c.acceptable_iter = 15;         // kin.py:252-253, IPOPT acceptable_iter
+  c.acceptable_constr_viol_tol = 1e-2; c.acceptable_dual_inf_tol = 1e10; c.acceptable_compl_inf_tol = 1e-2;
+  c.second_start = 0;                          // (the oracle's own defaults are IPOPT's: one attempt from the given start)
   return MPCB_OK;
 }
 
@@ -1265,6 +1289,16 @@ int mpco_solve(const mpcb_config* cfg, int32_t B, const double* x0, const double
     bool ok = s->init(x0 + (size_t)b * nx, xs + (size_t)b * nx, obs ? obs + b * obs_stride : nullptr, obs_kind,
                       z0 ? z0 + (size_t)b * nz : nullptr, tgrid);
     if (ok) s->solve(); else s->eval_point();
+    // cfg.second_start (after a roll-out start): an attempt that did not succeed — restoration phase included — is followed by a
+    // second attempt from z = 0 with a fresh solver state, as the HIP library's second-start passes
+    if (ok && cfg->second_start && cfg->init_rollout && s->status != MPCB_ST_SOLVED && s->status != MPCB_ST_ACCEPTABLE) {
+      const int it0 = s->iters;
+      s->~Solver();
+      s = new (arena) Solver(*cfg);
+      ok = s->init(x0 + (size_t)b * nx, xs + (size_t)b * nx, obs ? obs + b * obs_stride : nullptr, obs_kind, nullptr, tgrid, true);
+      if (ok) s->solve(); else s->eval_point();
+      s->iters_prev = it0;
+    }
     s->write(z + (size_t)b * nz, obj ? obj + b : nullptr, status ? status + b : nullptr, iters ? iters + b : nullptr,
              kkt ? kkt + (size_t)b * 4 : nullptr, lam_g ? lam_g + (size_t)b * ng : nullptr,
              lam_x ? lam_x + (size_t)b * nz : nullptr);

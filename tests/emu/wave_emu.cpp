@@ -22,7 +22,7 @@ template <int NOBS>
 static void run_instance(const MpcbKArgs& a, int b) {
   using namespace mpcbk;
   const bool dyn = a.cfg.model == MPCB_MODEL_DYN;
-  const bool rp = a.pass == 1;                                    // restoration pass: the RESTO instantiations
+  const bool rp = a.pass == MPCB_PASS_RESTO;                      // restoration pass: the RESTO instantiations
   const int total = dyn ? layout_dyn(a.cfg.N, rp, obs_in_lds(NOBS)).total : layout_kin(a.cfg.N, a.nz, rp, obs_in_lds(NOBS)).total;
   // LDS starts as garbage on the device: poison it here (MPCB_EMU_LDS_FILL, default NaN), so that a read of a never-written slot shows
   const char* fill_env = std::getenv("MPCB_EMU_LDS_FILL");
@@ -59,12 +59,18 @@ extern "C" int mpcb_emu_solve(const mpcb_config* cfg, int32_t B, const double* x
   a.x0 = x0; a.xs = xs; a.obs = obs; a.z0 = z0; a.z = z; a.obj = obj; a.kkt = kkt; a.lam_g = lam_g; a.lam_x = lam_x;
   a.status = status; a.iters = iters; a.trace = trace; a.tgrid = tgrid;
   std::vector<double> work((size_t)B * mpcbk::WK_SIZE, 0.0);
-  const bool two_pass = cfg->restoration != 0;                                 // as mpcb_api.hip: first pass, then the restoration pass
-  a.work = two_pass ? work.data() : nullptr;
-  for (int pass = 0; pass < (two_pass ? 2 : 1); ++pass) {
+  // as mpcb_api.hip: first pass, second-start pass (cfg.second_start), restoration pass (cfg.restoration)
+  const bool second = cfg->second_start && cfg->init_rollout;
+  a.work = (cfg->restoration || second) ? work.data() : nullptr;
+  // launch order of mpcb_api.hip: first attempt, its restoration pass, second attempt, its restoration pass
+  const int order[4] = {MPCB_PASS_FIRST, MPCB_PASS_RESTO, MPCB_PASS_SECOND, MPCB_PASS_RESTO};
+  for (int q = 0; q < 4; ++q) {
+    const int pass = order[q];
+    if ((q >= 2 && !second) || (pass == MPCB_PASS_RESTO && !cfg->restoration)) continue;
     a.pass = pass;
     for (int b = 0; b < B; ++b) {
-      if (pass == 1 && status[b] != MPCB_ST_NEEDS_RESTO) continue;
+      if (pass == MPCB_PASS_SECOND && (status[b] == MPCB_ST_SOLVED || status[b] == MPCB_ST_ACCEPTABLE || status[b] == MPCB_ST_INFEASIBLE_X0)) continue;
+      if (pass == MPCB_PASS_RESTO && status[b] != MPCB_ST_NEEDS_RESTO) continue;
       if (cfg->n_obs == 0) run_instance<0>(a, b);
       else if (cfg->n_obs == 1) run_instance<1>(a, b);
       else if (cfg->n_obs <= 3) run_instance<3>(a, b);
