@@ -283,6 +283,8 @@ def main():
     ap.add_argument("--batches", type=int, default=5,
                     help="distinct synthetic batches resident in HBM, used round-robin by the steps (the launch time of a 4096-instance "
                          "batch moves +-15 %% with where its slowest instances fall in the dispatch order; one batch would report one draw)")
+    ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"],
+                    help="shooting rows: explicit Euler (the reference's NLP, kin.py:207: the headline) or the RK4 instantiations (kinematic configurations)")
     ap.add_argument("--warm", action="store_true",
                     help="C2/C3/C4 only: time the NEXT receding-horizon step, started from the shifted solution of a cold solve "
                          "(main_cbf_kin_c_sim.py:16-26,92) instead of the cold start z0=0")
@@ -329,6 +331,9 @@ def main():
         workload = "C5: closed loop, %d scenes per GPU x 80 receding-horizon steps, kinematic bicycle + 3 moving obstacles re-predicted every step" % B
     if args.no_restoration:
         cfg.restoration = 0
+    if args.integrator == "rk4":
+        cfg.integrator = _abi.INT_RK4
+        workload += " [RK4 shooting rows]"
     x0, xs, obs = sets[0]
     nx, nz, ng = dims(cfg)
     bs = BatchSolver(cfg, device=local_rank)

@@ -74,7 +74,9 @@ extern "C" {
 
 /* integrator of the shooting rows */
 #define MPCB_INT_EULER 0      /* X_{i+1} = X_i + T f(X_i,U_i): what the reference's NLP and plant use   kin.py:207, main_cbf_kin_c_sim.py:17-18 */
-#define MPCB_INT_RK4   1      /* named by BASELINE.json's north_star; not in the reference -> mpcb_create returns MPCB_E_UNSUPPORTED */
+#define MPCB_INT_RK4   1      /* classical fourth-order Runge-Kutta step with the control held over the interval (BASELINE.json's north_star; the
+                                 reference itself has no RK4 NLP): kinematic model, up to 3 obstacles, keep-out / gamma = 1 rows; the plant step
+                                 of mpcb_closed_loop follows the same integrator */
 
 /* obstacle input kinds for mpcb_solve */
 #define MPCB_OBSIN_STATIC    0 /* [B, n_obs, 6]       rows [x,y,theta,v,l,w]   CMOM/main_cbf_kin_c_sim.py:55 */
@@ -99,7 +101,7 @@ typedef struct mpcb_config {
   int32_t  mu_strategy;       /* MPCB_MU_MONOTONE */
   int32_t  init_rollout;      /* 0: take the X part of the start as given (what IPOPT receives);
                                  1: keep U of the start, roll X out from x0 with the model (multiple-shooting warm start) */
-  int32_t  integrator;        /* MPCB_INT_EULER (the reference); MPCB_INT_RK4 is rejected */
+  int32_t  integrator;        /* MPCB_INT_EULER (the reference, default) or MPCB_INT_RK4 */
   int32_t  restoration;       /* 1 (default): a failed line search enters the feasibility-restoration phase (IPOPT's default
                                  behaviour); 0: it ends the solve with MPCB_ST_LINESEARCH (abi 1 behaviour) */
   double   T;                 /* T_S */
@@ -137,12 +139,16 @@ typedef struct mpcb_config {
   double   acceptable_dual_inf_tol;      /* 1e10 */
   double   acceptable_compl_inf_tol;     /* 1e-2 */
   int32_t  acceptable_iter;              /* 15; 0 switches the acceptable test off */
-  int32_t  second_start;                 /* 1 (mpcb_default_config): an instance whose solve from a roll-out start (init_rollout = 1) fails (no
-                                            acceptable step, a run of tiny steps, max_iter, numerics) is solved once more from the reference's own
-                                            first-step start z = 0 (main_cbf_kin_c_sim.py:47-50; dynamic model: 0 except vx = x0's, the tyre model
-                                            divides by vx), and only that second attempt enters the restoration phase; `iters` counts both
-                                            attempts, each has max_iter of its own.  Without a roll-out (init_rollout = 0: the start taken as
-                                            given, IPOPT's behaviour) there is one attempt, whatever this field says.  0: one attempt */
+  int32_t  second_start;                 /* An instance whose solve from a roll-out start (init_rollout = 1) fails (no acceptable step, a run of
+                                            tiny steps, max_iter, numerics) is solved once more from the reference's own first-step start z = 0
+                                            (main_cbf_kin_c_sim.py:47-50; dynamic model: 0 except vx = x0's, the tyre model divides by vx).
+                                              1 (mpcb_default_config): INSTEAD of the first attempt's restoration phase — only the second attempt
+                                                enters the restoration phase; three launches per solve;
+                                              2: AFTER the first attempt's restoration phase — every instance one attempt solves stays solved,
+                                                bit for bit; four launches per solve (the drop-in classes use this);
+                                              0: one attempt, as IPOPT.
+                                            `iters` counts both attempts, each has max_iter of its own.  Without a roll-out (init_rollout = 0:
+                                            the start taken as given, IPOPT's behaviour) there is one attempt, whatever this field says. */
 } mpcb_config;
 
 typedef struct mpcb_handle mpcb_handle;

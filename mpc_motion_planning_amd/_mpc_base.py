@@ -155,6 +155,15 @@ class MpcBase:
         # every shooting row and rate bound (kin.py:207,116-121).  Same default here; time_grid_in_nlp = True makes the grid
         # effective: stage i integrates over stage_lengths()[i] (mpcb_set_time_grid).
         self.time_grid_in_nlp = False
+        # Start of the solve.  "rollout" (default): U of the caller's start is kept, X is rolled out from x0 with the model and the
+        # barrier starts at mu = 10; an instance that fails from there — its restoration phase included — is solved once more from the
+        # reference's own first-step start z = 0 (cfg.second_start = 2).  "ipopt": the start is taken exactly as given and mu_init = 0.1,
+        # IPOPT's documented behaviour, one attempt.  Why the roll-out stays the default although IPOPT does the other thing: with this
+        # library's restatement of IPOPT's algorithm the "ipopt" start does NOT solve the reference's own scene at the shipped horizon
+        # (N_p = 50: restoration failed after 42 iterations) and fails on ~25 % of random scenes, the roll-out start with its fallback on
+        # < 1 %; on the instances both solve, 92-93 % end at the same trajectory (tests/test_parity_evidence.py).
+        self.start = "rollout"
+        self.integrator = "euler"                      # "rk4": MPCB_INT_RK4 (kinematic model), NLP rows and plant step alike
         self.f = ModelFunction(self._make_cfg(0))
 
     # ----- configuration of the HIP library from the YAML values ------------------------------------------
@@ -174,10 +183,15 @@ class MpcBase:
         if self.MODEL == _abi.MODEL_DYN:
             c.x_lo[4], c.x_hi[4] = self.vy_min, self.vy_max
             c.du_lo[1], c.du_hi[1] = self.jerk_min * self.T_S, self.jerk_max * self.T_S
+        if getattr(self, "start", "rollout") == "ipopt":
+            c.init_rollout, c.mu_init, c.second_start = 0, 0.1, 0
+        else:
+            c.second_start = 2                         # after the first attempt's restoration phase: nothing one attempt solves is lost
+        c.integrator = _abi.INT_RK4 if getattr(self, "integrator", "euler") == "rk4" else _abi.INT_EULER
         return c
 
     def _batch_solver(self, cfg):
-        key = (cfg.model, cfg.N, cfg.n_obs, cfg.obs_mode, cfg.gamma)
+        key = (cfg.model, cfg.N, cfg.n_obs, cfg.obs_mode, cfg.gamma, cfg.init_rollout, cfg.second_start, cfg.integrator)
         bs = self._solvers.get(key)
         if bs is None:
             bs = BatchSolver(cfg)

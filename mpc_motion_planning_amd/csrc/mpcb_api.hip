@@ -28,17 +28,17 @@ namespace {
 constexpr double INF = std::numeric_limits<double>::infinity();
 thread_local std::string g_create_error;
 
-template <int NOBS, bool GEN = false>
+template <int NOBS, bool GEN = false, bool RK4 = false>
 __global__ __launch_bounds__(64, MPCB_WAVES_PER_SIMD) void mpcb_kernel_kin(const MpcbKArgs a) {
   extern __shared__ __attribute__((aligned(16))) double mpcb_lds[];
-  mpcb_solve_kin<NOBS, GEN>(a, (int)blockIdx.x, mpcb_lds);
+  mpcb_solve_kin<NOBS, GEN, false, RK4>(a, (int)blockIdx.x, mpcb_lds);
 }
 
 // restoration pass: main phase + restoration phase; a workgroup whose instance does not need it returns at once
-template <int NOBS, bool GEN = false>
+template <int NOBS, bool GEN = false, bool RK4 = false>
 __global__ __launch_bounds__(64, 1) void mpcb_kernel_kin_resto(const MpcbKArgs a) {
   extern __shared__ __attribute__((aligned(16))) double mpcb_lds[];
-  mpcb_solve_kin<NOBS, GEN, true>(a, (int)blockIdx.x, mpcb_lds);
+  mpcb_solve_kin<NOBS, GEN, true, RK4>(a, (int)blockIdx.x, mpcb_lds);
 }
 
 template <int NOBS>
@@ -104,8 +104,22 @@ __global__ __launch_bounds__(128) void mpcb_advance(const mpcb_config c, int B, 
 #pragma unroll
   for (int q = 0; q < NX; ++q) x[q] = xb[q];
   model_rhs(c, x, u, f);
+  if (c.integrator == MPCB_INT_RK4) {                                             // the plant follows the NLP's integrator: classical RK4 step, control held
+    double k2[MPCB_NX_MAX], k3[MPCB_NX_MAX], k4[MPCB_NX_MAX], xt[MPCB_NX_MAX] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-  for (int q = 0; q < NX; ++q) xb[q] = x[q] + T * f[q];                          // st = x0 + T f(x0, u[0])
+    for (int q = 0; q < NX; ++q) xt[q] = x[q] + 0.5 * T * f[q];
+    model_rhs(c, xt, u, k2);
+#pragma unroll
+    for (int q = 0; q < NX; ++q) xt[q] = x[q] + 0.5 * T * k2[q];
+    model_rhs(c, xt, u, k3);
+#pragma unroll
+    for (int q = 0; q < NX; ++q) xt[q] = x[q] + T * k3[q];
+    model_rhs(c, xt, u, k4);
+#pragma unroll
+    for (int q = 0; q < NX; ++q) f[q] = (f[q] + 2.0 * k2[q] + 2.0 * k3[q] + k4[q]) / 6.0;
+  }
+#pragma unroll
+  for (int q = 0; q < NX; ++q) xb[q] = x[q] + T * f[q];                          // st = x0 + T f(x0, u[0])  (RK4: T times the weighted slope)
   if (u_hist) { u_hist[((size_t)b * steps + step) * 2] = u[0]; u_hist[((size_t)b * steps + step) * 2 + 1] = u[1]; }
   if (x_hist) {
     double* h = x_hist + ((size_t)b * (steps + 1) + step + 1) * NX;
@@ -352,11 +366,11 @@ int check_cfg(mpcb_handle* h, const mpcb_config* c) {
   if (c->obs_mode == MPCB_OBS_DCBF && c->obs_terminal)
     return fail(h, MPCB_E_UNSUPPORTED, "discrete-CBF rows exist for i = 0..N-1 only (row N would need X_{N+1}, kin.py:236-248): obs_terminal must be 0");
   if (c->mu_strategy != MPCB_MU_MONOTONE) return fail(h, MPCB_E_INVALID, "unknown mu_strategy %d (MPCB_MU_MONOTONE is the only one)", c->mu_strategy);
-  if (c->integrator == MPCB_INT_RK4)
-    return fail(h, MPCB_E_UNSUPPORTED, "MPCB_INT_RK4: the reference's NLP and plant are explicit Euler (kin.py:207); no RK4 mode is built");
-  if (c->integrator != MPCB_INT_EULER) return fail(h, MPCB_E_INVALID, "unknown integrator %d", c->integrator);
+  if (c->integrator != MPCB_INT_EULER && c->integrator != MPCB_INT_RK4) return fail(h, MPCB_E_INVALID, "unknown integrator %d", c->integrator);
+  if (c->integrator == MPCB_INT_RK4 && (c->model != MPCB_MODEL_KIN || c->n_obs > 3 || (c->obs_mode == MPCB_OBS_DCBF && c->gamma < 1.0 - 1e-12)))
+    return fail(h, MPCB_E_UNSUPPORTED, "MPCB_INT_RK4 is built for the kinematic model with up to 3 obstacles and keep-out / gamma = 1 rows");
   if (c->restoration != 0 && c->restoration != 1) return fail(h, MPCB_E_INVALID, "restoration must be 0 or 1");
-  if (c->second_start != 0 && c->second_start != 1) return fail(h, MPCB_E_INVALID, "second_start must be 0 or 1");
+  if (c->second_start < 0 || c->second_start > 2) return fail(h, MPCB_E_INVALID, "second_start must be 0, 1 or 2");
   if (std::isfinite(c->x_lo[0]) || std::isfinite(c->x_hi[0]) || std::isfinite(c->x_lo[2]) || std::isfinite(c->x_hi[2]))
     return fail(h, MPCB_E_UNSUPPORTED, "state boxes are supported on y, vx (and vy for the dynamic model) (kin.py:97-105, dyn.py:97-110)");
   if (c->model == MPCB_MODEL_KIN) {
@@ -373,10 +387,12 @@ int check_cfg(mpcb_handle* h, const mpcb_config* c) {
 }
 
 bool is_gen(const mpcb_config& c) { return c.model == MPCB_MODEL_KIN && c.obs_mode == MPCB_OBS_DCBF && c.gamma < 1.0 - 1e-12 && c.n_obs > 0; }
+bool is_rk4(const mpcb_config& c) { return c.model == MPCB_MODEL_KIN && c.integrator == MPCB_INT_RK4; }
+bool wide_table(const mpcb_config& c) { return is_gen(c) || is_rk4(c); }       // four more rows in the entry table of the kinematic kernels
 
 size_t lds_bytes(const mpcb_config& c, int nz) {
   return (size_t)(c.model == MPCB_MODEL_DYN ? mpcbk::layout_dyn(c.N, false, mpcbk::obs_in_lds(mpcbk::obs_capacity_dyn(c.n_obs))).total
-                                             : mpcbk::layout_kin(c.N, nz, false, mpcbk::obs_in_lds(mpcbk::obs_capacity_kin(c.n_obs, is_gen(c))), is_gen(c)).total) * sizeof(double);
+                                             : mpcbk::layout_kin(c.N, nz, false, mpcbk::obs_in_lds(mpcbk::obs_capacity_kin(c.n_obs, is_gen(c))), wide_table(c)).total) * sizeof(double);
 }
 
 // oldest recorded pair -> total_ms / last_ms / launches
@@ -497,6 +513,10 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in, int lane_id = 0) {
       if (n == 1) rc = launch_kernel(h, stream, mpcb_kernel_kin<1, true>, a, lds);
       else if (n <= 3) rc = launch_kernel(h, stream, mpcb_kernel_kin<3, true>, a, lds);
       else rc = launch_kernel(h, stream, mpcb_kernel_kin<8, true>, a, lds);
+    } else if (is_rk4(h->cfg)) {                                                               // Runge-Kutta shooting rows
+      if (n == 0) rc = launch_kernel(h, stream, mpcb_kernel_kin<0, false, true>, a, lds);
+      else if (n == 1) rc = launch_kernel(h, stream, mpcb_kernel_kin<1, false, true>, a, lds);
+      else rc = launch_kernel(h, stream, mpcb_kernel_kin<3, false, true>, a, lds);
     } else if (n == 0) rc = launch_kernel(h, stream, mpcb_kernel_kin<0>, a, lds);
     else if (n == 1) rc = launch_kernel(h, stream, mpcb_kernel_kin<1>, a, lds);
     else if (n <= 3) rc = launch_kernel(h, stream, mpcb_kernel_kin<3>, a, lds);
@@ -510,7 +530,7 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in, int lane_id = 0) {
     a.pass = MPCB_PASS_RESTO;
     const bool dyn = h->cfg.model == MPCB_MODEL_DYN;
     const size_t lds2 = (size_t)(dyn ? mpcbk::layout_dyn(h->cfg.N, true, mpcbk::obs_in_lds(mpcbk::obs_capacity_dyn(n))).total
-                                     : mpcbk::layout_kin(h->cfg.N, h->nz, true, mpcbk::obs_in_lds(mpcbk::obs_capacity_kin(n, is_gen(h->cfg))), is_gen(h->cfg)).total) * sizeof(double);
+                                     : mpcbk::layout_kin(h->cfg.N, h->nz, true, mpcbk::obs_in_lds(mpcbk::obs_capacity_kin(n, is_gen(h->cfg))), wide_table(h->cfg)).total) * sizeof(double);
     if (lds2 > 160 * 1024) return fail(h, MPCB_E_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB", lds2);
     const bool gen = h->cfg.obs_mode == MPCB_OBS_DCBF && h->cfg.gamma < 1.0 - 1e-12 && n > 0;
     if (dyn) {
@@ -522,6 +542,10 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in, int lane_id = 0) {
       if (n == 1) rc = launch_kernel(h, stream, mpcb_kernel_kin_resto<1, true>, a, lds2);
       else if (n <= 3) rc = launch_kernel(h, stream, mpcb_kernel_kin_resto<3, true>, a, lds2);
       else rc = launch_kernel(h, stream, mpcb_kernel_kin_resto<8, true>, a, lds2);
+    } else if (is_rk4(h->cfg)) {
+      if (n == 0) rc = launch_kernel(h, stream, mpcb_kernel_kin_resto<0, false, true>, a, lds2);
+      else if (n == 1) rc = launch_kernel(h, stream, mpcb_kernel_kin_resto<1, false, true>, a, lds2);
+      else rc = launch_kernel(h, stream, mpcb_kernel_kin_resto<3, false, true>, a, lds2);
     } else if (n == 0) rc = launch_kernel(h, stream, mpcb_kernel_kin_resto<0>, a, lds2);
     else if (n == 1) rc = launch_kernel(h, stream, mpcb_kernel_kin_resto<1>, a, lds2);
     else if (n <= 3) rc = launch_kernel(h, stream, mpcb_kernel_kin_resto<3>, a, lds2);
@@ -535,7 +559,8 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in, int lane_id = 0) {
   // lean kernel once more over the same grid, where only the instances whose first attempt did not succeed run from z = 0, and the
   // restoration pass of that attempt
   rc = lean_pass(MPCB_PASS_FIRST);
-  if (rc == MPCB_OK && h->cfg.restoration) rc = resto_pass();
+  // (cfg.second_start = 1: the first attempt's restoration pass is skipped — its instances go straight to the second start)
+  if (rc == MPCB_OK && h->cfg.restoration && !(second_pass(h->cfg) && h->cfg.second_start == 1)) rc = resto_pass();
   if (rc == MPCB_OK && second_pass(h->cfg)) {
     rc = lean_pass(MPCB_PASS_SECOND);
     if (rc == MPCB_OK && h->cfg.restoration) rc = resto_pass();

@@ -89,7 +89,9 @@ enum KinEnt {
   E_G0, E_G1, E_G2, E_G3, E_G4, E_G5, E_G6, E_G7,       // condensed gradient
   E_HXX, E_HXY, E_HYY, E_HPP, E_HPV, E_HVV, E_HVD, E_HDD, E_HAA, E_H44, E_H55, E_H46, E_H57,
   E_HXP, E_HXV, E_HYP, E_HYV,                           // only with general-gamma CBF rows: the GEN kernels' tables have these four rows more
-  KIN_NENT
+  KIN_NENT,
+  // RK4 instantiations (never together with GEN) use the same four rows for the pairs (phi,delta) (phi,a) (v,a) (delta,a) of the step's Hessian
+  E_HPD = E_HXP, E_HPA = E_HXV, E_HVA = E_HYP, E_HDA = E_HYV
 };
 
 // LDS layout (doubles).  ld = (N+1)|1: odd leading dimension of the [entry][node] tables.
@@ -196,6 +198,70 @@ MPCB_DEV void sincos_b(double x, double& s, double& c) {
   c = (q == 0) ? ck : (q == 1) ? -sk : (q == 2) ? -ck : sk;
 }
 
+// ---- classical fourth-order Runge-Kutta step of the kinematic bicycle with the control held over the interval (cfg.integrator =
+// MPCB_INT_RK4).  With p = (phi, v, delta, a), c = tan(delta) / L and h = T / 2 the four stage states are
+//     phi_s = phi + alpha_s v c + beta_s a c,   v_s = v + gamma_s a,   (alpha, beta, gamma)_s = (0,0,0), (h,0,h), (h,h^2,h), (T,Th,T)
+// (the speed and the heading are polynomials in time, which RK4 integrates exactly), and
+//     x+ = x + T/6 sum_s w_s v_s cos phi_s,  y+ = y + T/6 sum_s w_s v_s sin phi_s,  phi+ = phi + T (v + T a / 2) c,  v+ = v + T a,  w = (1,2,2,1).
+struct KinRkJac { double a02, a03, a12, a13, a23, b00, b01, b10, b11, b20, b21; };   // dF/d(phi, v) and dF/d(delta, a); b31 = T, the rest is the identity / zero
+struct KinRkHess { double pp, pv, pd, pa, vv, vd, va, dd, da, aa; };                 // sum_r lam_r d2F_r over the pairs of (phi, v, delta, a)
+MPCB_DEV void kin_rk4_stage(int s, double T, double& al, double& be, double& ga, double& w) {
+  const double h = 0.5 * T;
+  al = s == 0 ? 0.0 : s == 3 ? T : h; be = s == 2 ? h * h : s == 3 ? T * h : 0.0; ga = s == 0 ? 0.0 : s == 3 ? T : h; w = (s == 1 || s == 2) ? 2.0 : 1.0;
+}
+// F = the step from (X, U); sp, cp = sin, cos of the heading, td = tan(delta)
+MPCB_DEV void kin_rk4_step(const double* X, const double* U, double T, double il, double sp, double cp, double td, double* F) {
+  const double v = X[3], a = U[1], c = td * il;
+  double sx = v * cp, sy = v * sp;
+#pragma unroll
+  for (int s = 1; s < 4; ++s) {
+    double al, be, ga, w; kin_rk4_stage(s, T, al, be, ga, w);
+    double ss, cs; sincos_b(X[2] + (al * v + be * a) * c, ss, cs);
+    const double vs = v + ga * a;
+    sx += w * (vs * cs); sy += w * (vs * ss);
+  }
+  F[0] = X[0] + (T / 6.0) * sx; F[1] = X[1] + (T / 6.0) * sy;
+  F[2] = X[2] + T * ((v + 0.5 * T * a) * c); F[3] = v + T * a;
+}
+// Jacobian entries and  sum_r lam_r d2F_r  (lam = costate of the step's four rows); sec2 = 1 / cos^2(delta)
+MPCB_DEV void kin_rk4_derivs(const double* X, const double* U, double T, double il, double sp, double cp, double td, double sec2,
+                             const double* lam, KinRkJac& J, KinRkHess& H) {
+  const double v = X[3], a = U[1], c = td * il, c1 = sec2 * il, c2 = 2.0 * td * sec2 * il;
+  double gx[4] = {0, 0, 0, 0}, gy[4] = {0, 0, 0, 0}, hh[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    double al, be, ga, w; kin_rk4_stage(s, T, al, be, ga, w);
+    double ss = sp, cs = cp;
+    if (s > 0) sincos_b(X[2] + (al * v + be * a) * c, ss, cs);
+    const double vs = v + ga * a;
+    const double fp[4] = {1.0, al * c, (al * v + be * a) * c1, be * c};        // d phi_s / d(phi, v, delta, a)
+    const double vp[4] = {0.0, 1.0, 0.0, ga};                                   // d v_s / d(...)
+    // second derivatives of phi_s: (v,delta) = al c', (delta,delta) = (al v + be a) c'', (delta,a) = be c'
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      gx[i] += w * (vp[i] * cs - vs * ss * fp[i]);
+      gy[i] += w * (vp[i] * ss + vs * cs * fp[i]);
+#pragma unroll
+      for (int j = i; j < 4; ++j, ++q) {
+        const double fij = (i == 1 && j == 2) ? al * c1 : (i == 2 && j == 2) ? (al * v + be * a) * c2 : (i == 2 && j == 3) ? be * c1 : 0.0;
+        const double cross = vp[i] * fp[j] + vp[j] * fp[i], quad = vs * fp[i] * fp[j];
+        const double gxx = -cross * ss - quad * cs - vs * ss * fij;
+        const double gyy = cross * cs - quad * ss + vs * cs * fij;
+        hh[q] += w * (lam[0] * gxx + lam[1] * gyy);
+      }
+    }
+  }
+  const double t6 = T / 6.0;
+  J.a02 = t6 * gx[0]; J.a03 = t6 * gx[1]; J.b00 = t6 * gx[2]; J.b01 = t6 * gx[3];
+  J.a12 = t6 * gy[0]; J.a13 = t6 * gy[1]; J.b10 = t6 * gy[2]; J.b11 = t6 * gy[3];
+  J.a23 = T * c; J.b20 = T * (v + 0.5 * T * a) * c1; J.b21 = 0.5 * T * T * c;
+  // pairs in the order (p,p) (p,v) (p,d) (p,a) (v,v) (v,d) (v,a) (d,d) (d,a) (a,a); the heading row adds (v,d), (d,d), (d,a)
+  H.pp = t6 * hh[0]; H.pv = t6 * hh[1]; H.pd = t6 * hh[2]; H.pa = t6 * hh[3]; H.vv = t6 * hh[4];
+  H.vd = t6 * hh[5] + lam[2] * T * c1; H.va = t6 * hh[6];
+  H.dd = t6 * hh[7] + lam[2] * T * (v + 0.5 * T * a) * c2; H.da = t6 * hh[8] + lam[2] * 0.5 * T * T * c1; H.aa = t6 * hh[9];
+}
+
 // IPOPT constants (Waechter & Biegler 2006 / IPOPT option defaults)
 constexpr double K_EPS = 10.0, K_MU = 0.2, TAU_MIN = 0.99;
 constexpr double G_THETA = 1e-5, G_PHI = 1e-8, DELTA = 1.0, S_THETA = 1.1, S_PHI = 2.3, ETA_PHI = 1e-8, G_ALPHA = 0.05;
@@ -213,8 +279,11 @@ constexpr double DW_FIRST = 1e-4, DW_MIN = 1e-20, DW_MAX = 1e40, KW_MINUS = 1.0 
 // step depends on X_i only.  Its gradient has four entries (x, y, phi, v) and its Hessian fills the state block.
 // RESTO = the instantiation that runs the restoration pass (a.pass == 1): main phase + restoration phase with a run-time phase
 // flag, per-node cost table, elastic obstacle rows.  The RESTO = false instantiation is the lean main phase of the first pass.
-template <int NOBS, bool GEN = false, bool RESTO = false>
+// RK4 = the shooting rows use the Runge-Kutta step (cfg.integrator = MPCB_INT_RK4; keep-out / gamma = 1 rows only, never with GEN): the
+//   stage's B block becomes dense (the control enters x+, y+ and phi+ through both columns), four more Hessian pairs exist.
+template <int NOBS, bool GEN = false, bool RESTO = false, bool RK4 = false>
 MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
+  static_assert(!(GEN && RK4), "general-gamma CBF rows are written for the Euler step");
   using namespace mpcbk;
   constexpr int NX = 4, NA = 6, NW = 8, NOB = NOBS > 0 ? NOBS : 1, NEL = RESTO ? NOB : 1;
   const mpcb_config& c = a.cfg;
@@ -224,6 +293,9 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   if (!RESTO && a.pass == MPCB_PASS_SECOND) {          // second start: only instances whose first attempt (restoration included) did not succeed
     const int st1 = a.status[(size_t)b * a.st_stride];
     if (st1 == MPCB_ST_SOLVED || st1 == MPCB_ST_ACCEPTABLE || st1 == MPCB_ST_INFEASIBLE_X0) return;
+    bool fin = true;                                    // non-finite inputs: the first attempt's verdict (at iteration 0) stands
+    for (int i = 0; i < 4; ++i) fin = fin && isfinite(a.x0[(size_t)b * 4 + i]) && isfinite(a.xs[(size_t)b * 4 + i]);
+    if (!fin) return;
   }
   // Which start does this solve run from?  First attempt: the caller's z0, with X rolled out from x0 (cfg.init_rollout).  Second
   // attempt (cfg.second_start, only after a roll-out start; mpcb_api.hip launches its passes after the first attempt's): the
@@ -232,7 +304,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   const bool zeros_start = RESTO ? (a.work && a.work[(size_t)b * mpcbk::WK_SIZE + mpcbk::WK_START] != 0.0) : a.pass == MPCB_PASS_SECOND;
   const bool rollout = c.init_rollout && !zeros_start;
   constexpr bool OBL = NOBS > 3;                  // obstacle constants in LDS ([4 * j + q][lane]) instead of registers
-  const Layout L = layout_kin(N, nz, RESTO, obs_in_lds(NOBS), GEN);
+  const Layout L = layout_kin(N, nz, RESTO, obs_in_lds(NOBS), GEN || RK4);
   const int ld = L.ld;
   double* ent = lds + L.ent;
   // step length of this lane's stage: cfg.T, or the stage's entry of the time grid (lanes past the last stage take its value)
@@ -447,7 +519,8 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     for (int s = 0; s < N; ++s) {
       double sps, cps; sincos_b(X[2], sps, cps);
       const double v = X[3];
-      const double F0 = X[0] + T * (v * cps), F1 = X[1] + T * (v * sps), F2 = X[2] + T * (v * tdr * il), F3 = X[3] + T * U[1];
+      double F0 = X[0] + T * (v * cps), F1 = X[1] + T * (v * sps), F2 = X[2] + T * (v * tdr * il), F3 = X[3] + T * U[1];
+      if (RK4) { double Fr[NX]; kin_rk4_step(X, U, T, il, sps, cps, tdr, Fr); F0 = Fr[0]; F1 = Fr[1]; F2 = Fr[2]; F3 = Fr[3]; }
       const double n0 = wv::bcast(F0, s), n1 = wv::bcast(F1, s), n2 = wv::bcast(F2, s), n3 = wv::bcast(F3, s);
       if (k == s + 1) { X[0] = n0; X[1] = n1; X[2] = n2; X[3] = n3; }
     }
@@ -517,7 +590,8 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
                        double* dfa, double& rRa, double* rOa, double& up0, double& up1, double& th, double& fl, double& prod) {
     bool ok = true;
     const double v = Xa[3];
-    const double Ft[NX] = {Xa[0] + T * (v * c_), Xa[1] + T * (v * s_), Xa[2] + T * (v * t_ * il), Xa[3] + T * Ua[1]};
+    double Ft[NX] = {Xa[0] + T * (v * c_), Xa[1] + T * (v * s_), Xa[2] + T * (v * t_ * il), Xa[3] + T * Ua[1]};
+    if (RK4) kin_rk4_step(Xa, Ua, T, il, s_, c_, t_, Ft);
     th = 0; fl = 0; prod = 1.0;
 #pragma unroll
     for (int i = 0; i < NX; ++i) { const double xn = wv::shfl(Xa[i], k + 1); dfa[i] = hasu ? Ft[i] - xn : 0.0; th += fabs(dfa[i]); }
@@ -594,6 +668,11 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         if (r == 2 && col == 3) return 2 * FWR + 3;
         return FW_ZERO;
       }
+      if (RK4) {       // dense B: the two control coefficients of a state row sit in slots 4, 5 of its record (its U_prev coefficients, which are zero, are not stored)
+        if (col == 6) return r == 3 ? FW_ZERO : r * FWR + 4;
+        if (col == 7) return r * FWR + 5;
+        return FW_ZERO;
+      }
       if (r == 2 && col == 6) return 2 * FWR + FW_BX;
       if (r == 3 && col == 7) return 3 * FWR + FW_BX;
       return FW_ZERO;
@@ -615,6 +694,12 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     if (lo == 5 && hi == 5) return E_H55;
     if (lo == 4 && hi == 6) return E_H46;
     if (lo == 5 && hi == 7) return E_H57;
+    if (RK4) {
+      if (lo == 2 && hi == 6) return E_HPD;
+      if (lo == 2 && hi == 7) return E_HPA;
+      if (lo == 3 && hi == 7) return E_HVA;
+      if (lo == 6 && hi == 7) return E_HDA;
+    }
     if (GEN) {
       if (lo == 0 && hi == 2) return E_HXP;
       if (lo == 0 && hi == 3) return E_HXV;
@@ -669,7 +754,8 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     for (int i = 0; i < NA; ++i) {
 #pragma unroll
       for (int r = 0; r < FWR; ++r) {
-        const bool var = i >= NX ? r <= FW_C0 : (r == FW_C0 || (i == 0 && (r == 2 || r == 3)) || (i == 1 && (r == 2 || r == 3)) || (i == 2 && (r == 3 || r == FW_BX)) || (i == 3 && r == FW_BX));
+        const bool var = i >= NX ? r <= FW_C0 : (r == FW_C0 || (i == 0 && (r == 2 || r == 3)) || (i == 1 && (r == 2 || r == 3)) || (i == 2 && (r == 3 || r == FW_BX)) || (i == 3 && r == FW_BX) ||
+                                                 (RK4 && (r == 4 || r == 5)));
         if (!var) fk[i * FWR + r] = (i < NX && r == i) ? 1.0 : 0.0;
       }
     }
@@ -783,10 +869,15 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       }
       MPCB_STAMP(t_a);
       // ----- KKT residuals of the scaled problem at the iterate (one pass, fused reductions) ---------------------
-      const double a02 = -T * X[3] * sp, a03 = T * cp, a12 = T * X[3] * cp, a13 = T * sp, a23 = T * td * il, b20 = T * X[3] * sec2 * il;
+      double a02 = -T * X[3] * sp, a03 = T * cp, a12 = T * X[3] * cp, a13 = T * sp, a23 = T * td * il, b20 = T * X[3] * sec2 * il;
       double ln[NX];
 #pragma unroll
       for (int i = 0; i < NX; ++i) ln[i] = wv::shfl(lam[i], k + 1);          // lam_{k+1}
+      KinRkJac Jr{}; KinRkHess Hr{};
+      if (RK4) {
+        kin_rk4_derivs(X, U, T, il, sp, cp, td, sec2, ln, Jr, Hr);
+        a02 = Jr.a02; a03 = Jr.a03; a12 = Jr.a12; a13 = Jr.a13; a23 = Jr.a23; b20 = Jr.b20;
+      }
       {
         double rX[NX] = {0, 0, 0, 0}, rU[NU] = {0, 0};
         const double Un0 = wv::shfl(U[0], k + 1), Un1 = wv::shfl(U[1], k + 1);
@@ -814,6 +905,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           }
           if (k + 1 < N) { rU[0] -= cWDR(0) * (Un0 - U[0]); rU[1] -= cWDR(1) * (Un1 - U[1]); }
           rU[0] += b20 * ln[2]; rU[1] += T * ln[3];
+          if (RK4) { rU[0] += Jr.b00 * ln[0] + Jr.b10 * ln[1]; rU[1] += Jr.b01 * ln[0] + Jr.b11 * ln[1] + Jr.b21 * ln[2]; }
           if (k + 1 < N) rU[0] += yRn;                                          // d(row k+1)/dU_k = -1
         }
         auto item = [&](const Bnd& q, double s, const Item& it) {
@@ -857,8 +949,8 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         const double e_sc = fmax(S_MAX, wv::uni(ss[1]) / fmax(1.0, n_vr)) / S_MAX;
         const double base = fmax(e_dual / e_sd, e_prim);
         err0 = fmax(base, (n_vr > 0 ? sv_hi : 0.0) / e_sc);                      // complementarity error at mu = 0
-        if (a.trace && b == a.trace_instance && lane == 0 && iters <= c.max_iter) {
-          double* t = a.trace + (size_t)iters * 8;
+        if (wv::late_args(a)->trace && b == wv::late_args(a)->trace_instance && lane == 0 && iters <= c.max_iter) {
+          double* t = wv::late_args(a)->trace + (size_t)iters * 8;
           t[0] = mu; t[1] = err0; t[2] = theta; t[3] = fval;
         }
         if (!(RESTO && rs)) {
@@ -1006,10 +1098,15 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           }
           // sum_a lam_{k+1,a} T d2f_a
           const double v = X[3];
-          hpp += T * (-ln[0] * v * cp - ln[1] * v * sp);
-          hpv += T * (-ln[0] * sp + ln[1] * cp);
-          hvd += T * ln[2] * sec2 * il;
-          hdd += T * ln[2] * v * 2.0 * td * sec2 * il;
+          if (!RK4) {
+            hpp += T * (-ln[0] * v * cp - ln[1] * v * sp);
+            hpv += T * (-ln[0] * sp + ln[1] * cp);
+            hvd += T * ln[2] * sec2 * il;
+            hdd += T * ln[2] * v * 2.0 * td * sec2 * il;
+          } else {       // sum_a lam_{k+1,a} d2 Phi_a of the Runge-Kutta step (kin_rk4_derivs); (phi,delta) (phi,a) (v,a) (delta,a) use the rows GEN uses otherwise
+            hpp += Hr.pp; hpv += Hr.pv; hvv += Hr.vv; hvd += Hr.vd; hdd += Hr.dd; haa += Hr.aa;
+            hxp = Hr.pd; hxv = Hr.pa; hyp = Hr.va; hyv = Hr.da;
+          }
         }
         double sig, gb;
         if (bu0_on) { item_sig_gb(iU0, 0.0, mu, sig, gb); hdd += sig; g[6] -= gb; }
@@ -1054,13 +1151,18 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
           for (int i = 0; i < NW; ++i) ent[(E_G0 + i) * ld + k] = g[i];
           double* fk = fw + k * FWS;                     // [A | d | B] and T of the stage: the variable slots of records 0..3
           fk[2] = hasu ? a02 : 0.0; fk[3] = hasu ? a03 : 0.0; fk[FWR + 2] = hasu ? a12 : 0.0; fk[FWR + 3] = hasu ? a13 : 0.0;
-          fk[2 * FWR + 3] = hasu ? a23 : 0.0; fk[2 * FWR + FW_BX] = hasu ? b20 : 0.0; fk[3 * FWR + FW_BX] = T;
+          fk[2 * FWR + 3] = hasu ? a23 : 0.0;
+          if (!RK4) { fk[2 * FWR + FW_BX] = hasu ? b20 : 0.0; fk[3 * FWR + FW_BX] = T; }
+          else {         // dense B: (b_r0, b_r1) in slots 4, 5 of record r
+            fk[4] = hasu ? Jr.b00 : 0.0; fk[5] = hasu ? Jr.b01 : 0.0; fk[FWR + 4] = hasu ? Jr.b10 : 0.0; fk[FWR + 5] = hasu ? Jr.b11 : 0.0;
+            fk[2 * FWR + 4] = hasu ? b20 : 0.0; fk[2 * FWR + 5] = hasu ? Jr.b21 : 0.0; fk[3 * FWR + 4] = 0.0; fk[3 * FWR + 5] = T;
+          }
 #pragma unroll
           for (int i = 0; i < NX; ++i) fk[i * FWR + FW_C0] = dfc[i];
           Pst[k * PST + PS_ZERO] = 0.0;
           ent[E_HXY * ld + k] = hxy; ent[E_HPV * ld + k] = hpv; ent[E_HVD * ld + k] = hvd;
           ent[E_H44 * ld + k] = h44; ent[E_H55 * ld + k] = h55; ent[E_H46 * ld + k] = h46; ent[E_H57 * ld + k] = h57;
-          if (GEN) { ent[E_HXP * ld + k] = hxp; ent[E_HXV * ld + k] = hxv; ent[E_HYP * ld + k] = hyp; ent[E_HYV * ld + k] = hyv; }
+          if (GEN || RK4) { ent[E_HXP * ld + k] = hxp; ent[E_HXV * ld + k] = hxv; ent[E_HYP * ld + k] = hyp; ent[E_HYV * ld + k] = hyv; }
         }
       }
 
@@ -1212,9 +1314,18 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         auto fstage = [&](int s, const FwRec& f, FwRec& nxt) {
           load_fw(s + 1, nxt);                             // (row N exists and holds finite numbers; its record is never used)
           MPCB_SCHED_FENCE();
-          const double t = fma(f.c[5], v5, fma(f.c[4], v4, fma(f.c[3], v3, fma(f.c[2], v2, fma(f.c[1], v1, fma(f.c[0], v0, f.c0))))));
-          const double du0 = wv::bcast(t, NX), du1 = wv::bcast(t, NX + 1);
-          const double n = fma(f.bx, lq == 3 ? du1 : du0, t);      // the control enters row 2 (b20 dU[0]) and row 3 (T dU[1])
+          double t, du0, du1, n;
+          if (!RK4) {
+            t = fma(f.c[5], v5, fma(f.c[4], v4, fma(f.c[3], v3, fma(f.c[2], v2, fma(f.c[1], v1, fma(f.c[0], v0, f.c0))))));
+            du0 = wv::bcast(t, NX); du1 = wv::bcast(t, NX + 1);
+            n = fma(f.bx, lq == 3 ? du1 : du0, t);      // the control enters row 2 (b20 dU[0]) and row 3 (T dU[1])
+          } else {
+            // slots 4, 5 of a state row's record hold its two control coefficients (dense B), of a gain row's the U_prev coefficients
+            const double tx = fma(f.c[3], v3, fma(f.c[2], v2, fma(f.c[1], v1, fma(f.c[0], v0, f.c0))));
+            t = lq >= NX ? fma(f.c[5], v5, fma(f.c[4], v4, tx)) : tx;
+            du0 = wv::bcast(t, NX); du1 = wv::bcast(t, NX + 1);
+            n = lq < NX ? fma(f.c[5], du1, fma(f.c[4], du0, t)) : t;
+          }
           hist[s] = n;
           v0 = wv::bcast(n, 0); v1 = wv::bcast(n, 1); v2 = wv::bcast(n, 2); v3 = wv::bcast(n, 3); v4 = du0; v5 = du1;
         };
@@ -1365,8 +1476,8 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         alpha = wv::uni(alpha * 0.5);
         if (alpha < a_min || alpha < 1e-16) break;
       }
-      if (a.trace && b == a.trace_instance && lane == 0) {
-        double* t = a.trace + (size_t)iters * 8;
+      if (wv::late_args(a)->trace && b == wv::late_args(a)->trace_instance && lane == 0) {
+        double* t = wv::late_args(a)->trace + (size_t)iters * 8;
         t[4] = a_pr; t[5] = accepted ? alpha : 0.0; t[6] = a_du; t[7] = dw;
 #if defined(MPCB_STAMPS) && !defined(MPCB_WAVE_EMU)
         MPCB_STAMP(t_e);
@@ -1469,6 +1580,9 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     fval = wv::sum(fl);
   }
   // ----- outputs (reference ordering), staged through LDS for coalesced stores ----------------------------------
+  // the output pointers and sizes are read from the kernel arguments HERE (wv::late_args) instead of being held in scalar registers
+  // through the whole solve: the kernels spill ~190 SGPRs into VGPR lanes, every reload is a v_readlane in the iteration loop
+  const MpcbKArgs& ao = *wv::late_args(a);
   // `ko` = k behind an optimisation barrier: the LDS addresses of the z staging are re-formed here instead of being kept
   // live (and spilled) from the identical expressions at kernel start — hipcc 7.2 mis-reloaded such a spilled address in the
   // dyn<3> build (lanes >= 1 wrote their X rows to zbuf[0..5]).
@@ -1481,23 +1595,23 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     for (int i = 0; i < NX; ++i) zbuf[NU * N + NX * ko + i] = X[i];
   }
   wv::sync();
-  for (int i = lo; i < nz; i += 64) a.z[(size_t)b * nz + i] = zbuf[i];
+  for (int i = lo; i < nz; i += 64) ao.z[(size_t)b * nz + i] = zbuf[i];
   if (lo == 0) {
-    if (a.obj) a.obj[b] = fval;
-    if (a.status) a.status[(size_t)b * a.st_stride] = status;
+    if (ao.obj) ao.obj[b] = fval;
+    if (ao.status) ao.status[(size_t)b * ao.st_stride] = status;
     // iterations of both attempts are counted (cfg.second_start): the first attempt leaves its total in the hand-over record, the
     // passes of the second attempt add it (read here, not kept live through the solve)
     int it_prev = 0;
-    if (a.work) {
-      double* wk = a.work + (size_t)b * mpcbk::WK_SIZE;
-      const bool second_attempt = RESTO ? wk[mpcbk::WK_START] != 0.0 : a.pass == MPCB_PASS_SECOND;
+    if (ao.work) {
+      double* wk = ao.work + (size_t)b * mpcbk::WK_SIZE;
+      const bool second_attempt = RESTO ? wk[mpcbk::WK_START] != 0.0 : ao.pass == MPCB_PASS_SECOND;
       if (second_attempt) it_prev = (int)wk[mpcbk::WK_ITPREV];
-      else if (status != MPCB_ST_NEEDS_RESTO) wk[mpcbk::WK_ITPREV] = (double)iters;
+      else wk[mpcbk::WK_ITPREV] = (double)iters;       // (also at a hand-over: with cfg.second_start = 1 no restoration pass of the first attempt follows)
     }
-    if (a.iters) a.iters[(size_t)b * a.st_stride] = iters + it_prev;
-    if (a.kkt) { double* q = a.kkt + (size_t)b * 4; q[0] = err0; q[1] = e_prim; q[2] = e_dual / os; q[3] = mu; }
+    if (ao.iters) ao.iters[(size_t)b * ao.st_stride] = iters + it_prev;
+    if (ao.kkt) { double* q = ao.kkt + (size_t)b * 4; q[0] = err0; q[1] = e_prim; q[2] = e_dual / os; q[3] = mu; }
   }
-  if (a.want_mult && a.lam_x) {
+  if (ao.want_mult && ao.lam_x) {
     wv::sync();
     for (int i = lo; i < nz; i += 64) zbuf[i] = 0.0;
     wv::sync();
@@ -1506,11 +1620,11 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     if (by_on) zbuf[NU * N + NX * ko + 1] = -item_y(qY, iY) / os;
     if (bv_on) zbuf[NU * N + NX * ko + 3] = -item_y(qV, iV) / os;
     wv::sync();
-    for (int i = lo; i < nz; i += 64) a.lam_x[(size_t)b * nz + i] = zbuf[i];
+    for (int i = lo; i < nz; i += 64) ao.lam_x[(size_t)b * nz + i] = zbuf[i];
   }
-  if (a.want_mult && a.lam_g) {
+  if (ao.want_mult && ao.lam_g) {
     // rows: [X_0 - P](NX), dynamics (NX*N), rate (N-1 if on), obstacles (rows * nobs)   kin.py:190-247
-    double* out = a.lam_g + (size_t)b * a.ng;
+    double* out = ao.lam_g + (size_t)b * ao.ng;
     const int r_dyn = NX, r_rate = NX + NX * N, n_rate = qR.on ? N - 1 : 0, r_obs = r_rate + n_rate;
     double ln[NX];
 #pragma unroll
@@ -1531,7 +1645,11 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
       for (int i = 0; i < NX; ++i) out[r_dyn + NX * (k - 1) + i] = (-lam[i] + (i == 0 ? cx : i == 1 ? cy : 0.0)) / os;
     }
     if (k == 0) {   // stationarity wrt the pinned X_0
-      const double a02 = -T * X[3] * sp, a03 = T * cp, a12 = T * X[3] * cp, a13 = T * sp, a23 = T * td * il;
+      double a02 = -T * X[3] * sp, a03 = T * cp, a12 = T * X[3] * cp, a13 = T * sp, a23 = T * td * il;
+      if (RK4) {
+        KinRkJac Jo{}; KinRkHess Ho{}; kin_rk4_derivs(X, U, T, il, sp, cp, td, sec2, ln, Jo, Ho);
+        a02 = Jo.a02; a03 = Jo.a03; a12 = Jo.a12; a13 = Jo.a13; a23 = Jo.a23;
+      }
       const double At[NX] = {ln[0], ln[1], a02 * ln[0] + a12 * ln[1] + ln[2], a03 * ln[0] + a13 * ln[1] + a23 * ln[2] + ln[3]};
 #pragma unroll
       for (int i = 0; i < NX; ++i) out[i] = -2 * c.Q[i] * (X[i] - xs[i]) - At[i] / os;

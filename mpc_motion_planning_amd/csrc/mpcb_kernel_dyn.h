@@ -147,6 +147,9 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   if (!RESTO && a.pass == MPCB_PASS_SECOND) {          // second start: only instances whose first attempt (restoration included) did not succeed
     const int st1 = a.status[(size_t)b * a.st_stride];
     if (st1 == MPCB_ST_SOLVED || st1 == MPCB_ST_ACCEPTABLE || st1 == MPCB_ST_INFEASIBLE_X0) return;
+    bool fin = true;                                    // non-finite inputs: the first attempt's verdict (at iteration 0) stands
+    for (int i = 0; i < 6; ++i) fin = fin && isfinite(a.x0[(size_t)b * 6 + i]) && isfinite(a.xs[(size_t)b * 6 + i]);
+    if (!fin) return;
   }
   // Which start does this solve run from?  First attempt: the caller's z0, with X rolled out from x0 (cfg.init_rollout).  Second
   // attempt (cfg.second_start, only after a roll-out start; mpcb_api.hip launches its passes after the first attempt's): the
@@ -700,8 +703,8 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         const double e_sc = fmax(S_MAX, wv::uni(ss[1]) / fmax(1.0, n_vr)) / S_MAX;
         const double base = fmax(e_dual / e_sd, e_prim);
         err0 = fmax(base, (n_vr > 0 ? sv_hi : 0.0) / e_sc);
-        if (a.trace && b == a.trace_instance && lane == 0 && iters <= c.max_iter) {
-          double* t = a.trace + (size_t)iters * 8;
+        if (wv::late_args(a)->trace && b == wv::late_args(a)->trace_instance && lane == 0 && iters <= c.max_iter) {
+          double* t = wv::late_args(a)->trace + (size_t)iters * 8;
           t[0] = mu; t[1] = err0; t[2] = theta; t[3] = fval;
         }
         if (!(RESTO && rs)) {
@@ -1164,8 +1167,8 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
         alpha = wv::uni(alpha * 0.5);
         if (alpha < a_min || alpha < 1e-16) break;
       }
-      if (a.trace && b == a.trace_instance && lane == 0) {
-        double* t = a.trace + (size_t)iters * 8;
+      if (wv::late_args(a)->trace && b == wv::late_args(a)->trace_instance && lane == 0) {
+        double* t = wv::late_args(a)->trace + (size_t)iters * 8;
         t[4] = a_pr; t[5] = accepted ? alpha : 0.0; t[6] = a_du; t[7] = dw;
 #if defined(MPCB_STAMPS) && !defined(MPCB_WAVE_EMU)
         MPCB_STAMP(t_e);
@@ -1272,6 +1275,9 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
   }
 
   // ----- outputs -----------------------------------------------------------------------------------------------------------
+  // the output pointers and sizes are read from the kernel arguments HERE (wv::late_args) instead of being held in scalar registers
+  // through the whole solve: the kernels spill ~190 SGPRs into VGPR lanes, every reload is a v_readlane in the iteration loop
+  const MpcbKArgs& ao = *wv::late_args(a);
   // `ko` = k behind an optimisation barrier: the LDS addresses of the z staging are re-formed here instead of being kept
   // live (and spilled) from the identical expressions at kernel start — hipcc 7.2 mis-reloaded such a spilled address in the
   // dyn<3> build (lanes >= 1 wrote their X rows to zbuf[0..5]).
@@ -1284,23 +1290,23 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
     for (int i = 0; i < NX; ++i) zbuf[NU * N + NX * ko + i] = X[i];
   }
   wv::sync();
-  for (int i = lo; i < nz; i += 64) a.z[(size_t)b * nz + i] = zbuf[i];
+  for (int i = lo; i < nz; i += 64) ao.z[(size_t)b * nz + i] = zbuf[i];
   if (lo == 0) {
-    if (a.obj) a.obj[b] = fval;
-    if (a.status) a.status[(size_t)b * a.st_stride] = status;
+    if (ao.obj) ao.obj[b] = fval;
+    if (ao.status) ao.status[(size_t)b * ao.st_stride] = status;
     // iterations of both attempts are counted (cfg.second_start): the first attempt leaves its total in the hand-over record, the
     // passes of the second attempt add it (read here, not kept live through the solve)
     int it_prev = 0;
-    if (a.work) {
-      double* wk = a.work + (size_t)b * mpcbk::WK_SIZE;
-      const bool second_attempt = RESTO ? wk[mpcbk::WK_START] != 0.0 : a.pass == MPCB_PASS_SECOND;
+    if (ao.work) {
+      double* wk = ao.work + (size_t)b * mpcbk::WK_SIZE;
+      const bool second_attempt = RESTO ? wk[mpcbk::WK_START] != 0.0 : ao.pass == MPCB_PASS_SECOND;
       if (second_attempt) it_prev = (int)wk[mpcbk::WK_ITPREV];
-      else if (status != MPCB_ST_NEEDS_RESTO) wk[mpcbk::WK_ITPREV] = (double)iters;
+      else wk[mpcbk::WK_ITPREV] = (double)iters;       // (also at a hand-over: with cfg.second_start = 1 no restoration pass of the first attempt follows)
     }
-    if (a.iters) a.iters[(size_t)b * a.st_stride] = iters + it_prev;
-    if (a.kkt) { double* q = a.kkt + (size_t)b * 4; q[0] = err0; q[1] = e_prim; q[2] = e_dual / os; q[3] = mu; }
+    if (ao.iters) ao.iters[(size_t)b * ao.st_stride] = iters + it_prev;
+    if (ao.kkt) { double* q = ao.kkt + (size_t)b * 4; q[0] = err0; q[1] = e_prim; q[2] = e_dual / os; q[3] = mu; }
   }
-  if (a.want_mult && a.lam_x) {
+  if (ao.want_mult && ao.lam_x) {
     wv::sync();
     for (int i = lo; i < nz; i += 64) zbuf[i] = 0.0;
     wv::sync();
@@ -1310,12 +1316,12 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a, const int b, double* lds) {
     if (bvx_on) zbuf[NU * N + NX * ko + 3] = -item_y(qVx, iVx) / os;
     if (bvy_on) zbuf[NU * N + NX * ko + 4] = -item_y(qVy, iVy) / os;
     wv::sync();
-    for (int i = lo; i < nz; i += 64) a.lam_x[(size_t)b * nz + i] = zbuf[i];
+    for (int i = lo; i < nz; i += 64) ao.lam_x[(size_t)b * nz + i] = zbuf[i];
   }
-  if (a.want_mult && a.lam_g) {
+  if (ao.want_mult && ao.lam_g) {
     // g order: [X_0 - P](6); then per stage i: dynamics(6) and, for i > 0, the rate rows (interleaved, dyn.py:226-231)
     // or all dynamics rows followed by the rate block; then the obstacle rows
-    double* out = a.lam_g + (size_t)b * a.ng;
+    double* out = ao.lam_g + (size_t)b * ao.ng;
     const int nr = (qR0.on ? 1 : 0) + (qR1.on ? 1 : 0);
     double ln[NX];
 #pragma unroll

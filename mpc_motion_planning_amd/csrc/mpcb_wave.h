@@ -98,8 +98,12 @@ MPCB_DEV int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 // where they are used, each time, instead of at kernel entry — for values needed once per iteration (the termination tolerances)
 // that keeps their SGPRs out of the register pressure of the whole solve.  Every solve kernel takes ONE argument, a MpcbKArgs by value.
 template <class T> MPCB_DEV const T* late_args(const T&) {
-  unsigned long long p = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(p));
+  const unsigned long long p0 = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  // (readfirstlane: the pointer is uniform, but behind loops whose exits the compiler cannot prove uniform it would otherwise be
+  // carried in a VGPR, which the scalar constraint below rejects)
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p0), hi = __builtin_amdgcn_readfirstlane((unsigned)(p0 >> 32));
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  const unsigned long long p = ((unsigned long long)hi << 32) | lo;
   return (const T*)(const __attribute__((address_space(4))) T*)p;      // constant address space: scalar loads
 }
 // a wave-uniform double moved to scalar registers

@@ -22,8 +22,9 @@ class KinNlp:
 
     def __init__(self, N, T, x0, xs, obs=None, Q=(1e1, 1e5, 3e5, 1e4), R=(1e4, 1e4), DR=(1e5, 1e2), veh_l=2.6,
                  veh_L=4.8, veh_W=1.8, safe_disl=1.0, safe_disw=0.5, df_lim=35 * np.pi / 180, a_lim=3.0, y_lim=(-1.0, 5.0),
-                 v_lim=(0.0, 40.0), ddf_lim=5 * np.pi / 180, obs_mode="keepout", gamma=1.0, u_last=(0.0, 0.0)):
+                 v_lim=(0.0, 40.0), ddf_lim=5 * np.pi / 180, obs_mode="keepout", gamma=1.0, u_last=(0.0, 0.0), integrator="euler"):
         self.N, self.T = N, T
+        self.integrator = integrator          # "euler": X+ = X + T f (kin.py:207); "rk4": classical Runge-Kutta step, control held (MPCB_INT_RK4)
         self.x0 = np.asarray(x0, float).reshape(4); self.xs = np.asarray(xs, float).reshape(4)
         self.Q, self.R, self.DR = np.asarray(Q, float), np.asarray(R, float), np.asarray(DR, float)
         self.veh_l = veh_l
@@ -56,6 +57,14 @@ class KinNlp:
     def rhs(self, X, U):
         return np.stack([X[:, 3] * np.cos(X[:, 2]), X[:, 3] * np.sin(X[:, 2]), X[:, 3] * np.tan(U[:, 0]) / self.veh_l, U[:, 1]], axis=1)
 
+    def step(self, X, U):
+        """One shooting step for every stage at once: X [N,4], U [N,2] -> X+ [N,4]."""
+        T = self.T
+        if self.integrator == "euler":
+            return X + T * self.rhs(X, U)
+        k1 = self.rhs(X, U); k2 = self.rhs(X + 0.5 * T * k1, U); k3 = self.rhs(X + 0.5 * T * k2, U); k4 = self.rhs(X + T * k3, U)
+        return X + (T / 6.0) * (k1 + 2 * k2 + 2 * k3 + k4)
+
     def f(self, z):
         U, X = self.split(z)
         e = X[:-1] - self.xs
@@ -70,7 +79,7 @@ class KinNlp:
         U, X = self.split(z)
         N = self.N
         rows = [X[0] - self.x0]
-        nxt = X[:-1] + self.T * self.rhs(X[:-1], U)
+        nxt = self.step(X[:-1], U)
         rows.append((X[1:] - nxt).reshape(-1))
         rows.append(U[1:, 0] - U[:-1, 0])
         for i in range(N):
@@ -106,7 +115,7 @@ class KinNlp:
     _patterns = {}
 
     def _pattern_key(self):
-        return (type(self).__name__, self.N, self.n_obs, getattr(self, "obs_mode", ""))
+        return (type(self).__name__, self.N, self.n_obs, getattr(self, "obs_mode", ""), getattr(self, "integrator", "euler"))
 
     def jac_g(self, z, h=1e-30):
         """The same Jacobian from a handful of evaluations: columns that share no row (variables three or more stages apart) are

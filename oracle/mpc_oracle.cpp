@@ -160,8 +160,30 @@ void rhs_any(const mpcb_config& c, const double* x, const double* u, double* o) 
   if (c.model == MPCB_MODEL_DYN) rhs_dyn<double>(c, x, u, o); else rhs_kin<double>(c, x, u, o);
 }
 
+// One shooting step X+ = Phi(X, U; T): explicit Euler (what the reference's NLP and plant use, kin.py:207 / dyn.py:227), or the
+// classical fourth-order Runge-Kutta step with the control held over the interval (cfg.integrator = MPCB_INT_RK4: BASELINE's
+// north_star names it; the only Runge-Kutta code in the reference tree is the scratch Reference/MPC/sim_test.py:35-37).  Written once
+// for double and for the AD type, so that Jacobians and Hessians of the RK4 step come from four differentiated rhs evaluations.
+template <class S>
+void step_model(const mpcb_config& c, double T, const S* x, const S* u, S* out) {
+  const int nx = c.model == MPCB_MODEL_DYN ? 6 : 4;
+  auto rhs = [&](const S* xx, S* o) { if (c.model == MPCB_MODEL_DYN) rhs_dyn<S>(c, xx, u, o); else rhs_kin<S>(c, xx, u, o); };
+  S k1[NXM];
+  rhs(x, k1);
+  if (c.integrator != MPCB_INT_RK4) { for (int i = 0; i < nx; ++i) out[i] = x[i] + T * k1[i]; return; }
+  S k2[NXM], k3[NXM], k4[NXM], xt[NXM];
+  for (int i = 0; i < nx; ++i) xt[i] = x[i] + (0.5 * T) * k1[i];
+  rhs(xt, k2);
+  for (int i = 0; i < nx; ++i) xt[i] = x[i] + (0.5 * T) * k2[i];
+  rhs(xt, k3);
+  for (int i = 0; i < nx; ++i) xt[i] = x[i] + T * k3[i];
+  rhs(xt, k4);
+  for (int i = 0; i < nx; ++i) out[i] = x[i] + (T / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+}
+void step_any(const mpcb_config& c, double T, const double* x, const double* u, double* out) { step_model<double>(c, T, x, u, out); }
+
 struct ModelEval {
-  double F[NXM];          // X + T f(X,U)   (explicit Euler, kin.py:207 / dyn.py:227)
+  double F[NXM];          // X+ = Phi(X, U; T): X + T f(X,U) (explicit Euler, kin.py:207 / dyn.py:227) or the RK4 step
   double A[NXM][NXM];     // dF/dX
   double B[NXM][NU];      // dF/dU
 };
@@ -174,17 +196,17 @@ void model_eval_ad(const mpcb_config& c, double T, const double* X, const double
   S x[NXM], u[NU], o[NXM];
   for (int i = 0; i < nx; ++i) x[i] = S::var(X[i], i);
   for (int i = 0; i < NU; ++i) u[i] = S::var(U[i], nx + i);
-  if (c.model == MPCB_MODEL_DYN) rhs_dyn<S>(c, x, u, o); else rhs_kin<S>(c, x, u, o);
+  step_model<S>(c, T, x, u, o);                      // o = Phi(x, u) with first and second derivatives
   for (int a = 0; a < nx; ++a) {
-    me.F[a] = X[a] + T * o[a].v;
-    for (int j = 0; j < nx; ++j) me.A[a][j] = (a == j ? 1.0 : 0.0) + T * o[a].g[j];
-    for (int j = 0; j < NU; ++j) me.B[a][j] = T * o[a].g[nx + j];
+    me.F[a] = o[a].v;
+    for (int j = 0; j < nx; ++j) me.A[a][j] = o[a].g[j];
+    for (int j = 0; j < NU; ++j) me.B[a][j] = o[a].g[nx + j];
   }
   if (Hc) {
     for (int i = 0; i < NVM; ++i) for (int j = 0; j < NVM; ++j) Hc[i][j] = 0.0;
     if (lam)
       for (int a = 0; a < nx; ++a)
-        for (int i = 0; i < nx + NU; ++i) for (int j = 0; j < nx + NU; ++j) Hc[i][j] += lam[a] * T * o[a].h[i][j];
+        for (int i = 0; i < nx + NU; ++i) for (int j = 0; j < nx + NU; ++j) Hc[i][j] += lam[a] * o[a].h[i][j];
   }
 }
 
@@ -220,7 +242,7 @@ void model_eval_kin(const mpcb_config& c, double T, const double* X, const doubl
 // T = step length of the stage: cfg.T, or the stage's entry of the time grid (mpcb_set_time_grid)
 void model_eval(const mpcb_config& c, double T, const double* X, const double* U, const double* lam, ModelEval& me,
                 double Hc[NVM][NVM], bool force_ad = false) {
-  if (c.model == MPCB_MODEL_KIN && !force_ad) model_eval_kin(c, T, X, U, lam, me, Hc);
+  if (c.model == MPCB_MODEL_KIN && !force_ad && c.integrator != MPCB_INT_RK4) model_eval_kin(c, T, X, U, lam, me, Hc);
   else model_eval_ad(c, T, X, U, lam, me, Hc);
 }
 
@@ -429,8 +451,7 @@ struct Solver {
     if (rollout) {
       for (int k = 0; k < N; ++k) {
         double Uc[NU]; for (int i = 0; i < NU; ++i) Uc[i] = std::min(std::max(U[k][i], c.u_lo[i]), c.u_hi[i]);
-        double f[NXM]; rhs_any(c, X[k], Uc, f);
-        for (int i = 0; i < nx; ++i) X[k + 1][i] = X[k][i] + Tk[k] * f[i];
+        step_any(c, Tk[k], X[k], Uc, X[k + 1]);
       }
     }
 
@@ -783,8 +804,8 @@ struct Solver {
       for (int i = 0; i < NU; ++i) Ut[k][i] = (k < N) ? U[k][i] + alpha * dU[k][i] : 0.0;
     }
     for (int k = 0; k < N; ++k) {
-      double f[NXM]; rhs_any(c, Xt[k], Ut[k], f); ++n_dyn_eval;
-      for (int i = 0; i < nx; ++i) t.theta += std::fabs(Xt[k][i] + Tk[k] * f[i] - Xt[k + 1][i]);
+      double F[NXM]; step_any(c, Tk[k], Xt[k], Ut[k], F); ++n_dyn_eval;
+      for (int i = 0; i < nx; ++i) t.theta += std::fabs(F[i] - Xt[k + 1][i]);
     }
     t.f = objective(Xt, Ut);
     double phi = osc * t.f;
@@ -964,6 +985,8 @@ struct Solver {
   int slow_run = 0, trips = 0;
   int acc_cnt = 0; double f_last = 1e300;       // acceptable-point counter and the objective of the previous convergence check
   int iters_prev = 0;                           // iterations of the failed first attempt (reported in the sum)
+  static constexpr int ST_HANDED_OVER = 7;      // internal (= the kernels' MPCB_ST_NEEDS_RESTO): the attempt stopped where restoration would begin
+  bool defer_restoration = false;               // first attempt under cfg.second_start = 1
 
   // violation of the ORIGINAL constraints at the iterate: shooting defects and  c(w) - s  of the general rows (l1 and max norm)
   void original_violation(double& th1, double& thinf) {
@@ -1131,6 +1154,7 @@ struct Solver {
       // has nothing to restore there and would throw the nearly converged multipliers away (IPOPT: "Restoration phase is
       // called at point that is almost feasible" -> Restoration_Failed).  The iterate is returned as it is.
       if (why == MPCB_ST_LINESEARCH && e0.prim <= c.tol) { status = MPCB_ST_RESTO_FAILED; break; }
+      if (defer_restoration) { status = ST_HANDED_OVER; break; }   // cfg.second_start = 1: the second start takes over instead
       const int rc = restoration();      // counts its iterations in `iters`
       if (rc != 0) { status = rc; break; }
       --iters;                           // the for-increment belongs to an iteration; the hand-over itself is none
@@ -1204,7 +1228,7 @@ int check_cfg(const mpcb_config* c) {
   if (c->obs_mode == MPCB_OBS_DCBF && !(c->gamma > 0.0 && c->gamma <= 1.0 + 1e-12)) return MPCB_E_INVALID;
   if (c->obs_mode == MPCB_OBS_DCBF && c->gamma < 1.0 - 1e-12 && (c->model != MPCB_MODEL_KIN || c->obs_terminal)) return MPCB_E_UNSUPPORTED;
   if (c->obs_mode == MPCB_OBS_DCBF && c->obs_terminal) return MPCB_E_UNSUPPORTED;
-  if (c->integrator != MPCB_INT_EULER) return c->integrator == MPCB_INT_RK4 ? MPCB_E_UNSUPPORTED : MPCB_E_INVALID;
+  if (c->integrator != MPCB_INT_EULER && c->integrator != MPCB_INT_RK4) return MPCB_E_INVALID;
   return MPCB_OK;
 }
 
@@ -1286,12 +1310,15 @@ int mpco_solve(const mpcb_config* cfg, int32_t B, const double* x0, const double
     static thread_local void* arena = nullptr;
     if (!arena) arena = ::operator new(sizeof(Solver));
     Solver* s = new (arena) Solver(*cfg);
+    s->defer_restoration = cfg->second_start == 1 && cfg->init_rollout != 0;
     bool ok = s->init(x0 + (size_t)b * nx, xs + (size_t)b * nx, obs ? obs + b * obs_stride : nullptr, obs_kind,
                       z0 ? z0 + (size_t)b * nz : nullptr, tgrid);
     if (ok) s->solve(); else s->eval_point();
     // cfg.second_start (after a roll-out start): an attempt that did not succeed — restoration phase included — is followed by a
     // second attempt from z = 0 with a fresh solver state, as the HIP library's second-start passes
-    if (ok && cfg->second_start && cfg->init_rollout && s->status != MPCB_ST_SOLVED && s->status != MPCB_ST_ACCEPTABLE) {
+    bool fin = true;                                  // non-finite inputs: the first attempt's verdict (at iteration 0) stands
+    for (int i = 0; i < nx; ++i) fin = fin && std::isfinite(x0[(size_t)b * nx + i]) && std::isfinite(xs[(size_t)b * nx + i]);
+    if (ok && fin && cfg->second_start && cfg->init_rollout && s->status != MPCB_ST_SOLVED && s->status != MPCB_ST_ACCEPTABLE) {
       const int it0 = s->iters;
       s->~Solver();
       s = new (arena) Solver(*cfg);

@@ -23,6 +23,7 @@ static void run_instance(const MpcbKArgs& a, int b) {
   using namespace mpcbk;
   const bool dyn = a.cfg.model == MPCB_MODEL_DYN;
   const bool rp = a.pass == MPCB_PASS_RESTO;                      // restoration pass: the RESTO instantiations
+  const bool rk4 = !dyn && a.cfg.integrator == MPCB_INT_RK4;
   const int total = dyn ? layout_dyn(a.cfg.N, rp, obs_in_lds(NOBS)).total : layout_kin(a.cfg.N, a.nz, rp, obs_in_lds(NOBS)).total;
   // LDS starts as garbage on the device: poison it here (MPCB_EMU_LDS_FILL, default NaN), so that a read of a never-written slot shows
   const char* fill_env = std::getenv("MPCB_EMU_LDS_FILL");
@@ -38,6 +39,8 @@ static void run_instance(const MpcbKArgs& a, int b) {
       else if (dyn) mpcb_solve_dyn<NOBS>(a, b, lds.data());
       else if (gen && rp) mpcb_solve_kin<(NOBS > 0 ? NOBS : 1), true, true>(a, b, lds.data());
       else if (gen) mpcb_solve_kin<(NOBS > 0 ? NOBS : 1), true>(a, b, lds.data());
+      else if (rk4 && rp) mpcb_solve_kin<(NOBS <= 3 ? NOBS : 3), false, true, true>(a, b, lds.data());
+      else if (rk4) mpcb_solve_kin<(NOBS <= 3 ? NOBS : 3), false, false, true>(a, b, lds.data());
       else if (rp) mpcb_solve_kin<NOBS, false, true>(a, b, lds.data());
       else mpcb_solve_kin<NOBS>(a, b, lds.data());
     });
@@ -67,6 +70,7 @@ extern "C" int mpcb_emu_solve(const mpcb_config* cfg, int32_t B, const double* x
   for (int q = 0; q < 4; ++q) {
     const int pass = order[q];
     if ((q >= 2 && !second) || (pass == MPCB_PASS_RESTO && !cfg->restoration)) continue;
+    if (q == 1 && second && cfg->second_start == 1) continue;      // second start instead of the first attempt's restoration
     a.pass = pass;
     for (int b = 0; b < B; ++b) {
       if (pass == MPCB_PASS_SECOND && (status[b] == MPCB_ST_SOLVED || status[b] == MPCB_ST_ACCEPTABLE || status[b] == MPCB_ST_INFEASIBLE_X0)) continue;

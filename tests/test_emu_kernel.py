@@ -135,3 +135,29 @@ def test_lds_budget_of_the_benchmark_instances():
     assert emu.lds_bytes(kin63_8, True) <= CU                                                     # the largest instance still fits one CU
     dyn63_8 = oracle.default_config(model=_abi.MODEL_DYN, N=63, n_obs=8)
     assert emu.lds_bytes(dyn63_8, True) <= CU
+
+
+def test_rk4_shooting_rows_kernel_source_against_oracle_and_certificate():
+    """cfg.integrator = MPCB_INT_RK4 (BASELINE's north_star; the reference's NLP is explicit Euler): the kernel's closed-form
+    Runge-Kutta step, its Jacobian and its Hessian contraction (kin_rk4_step / kin_rk4_derivs in mpcb_kernel.h) stepped on the CPU
+    against the oracle, which differentiates four rhs evaluations by second-order AD: same iteration counts, same trajectories;
+    and the independent certificate of oracle/kkt_check.py with its own RK4 rows (complex-step derivatives)."""
+    from oracle import kkt_check
+    cfg = product_cfg(30, 1); cfg.integrator = _abi.INT_RK4
+    x0, xs, obs = scenes.sample_c2(5, seed=3); x0[0] = scenes.SHIPPED_X0
+    r = oracle.solve(cfg, x0, xs, obs); e = emu.solve(cfg, x0, xs, obs)
+    assert np.array_equal(r["status"], e["status"]) and np.array_equal(r["iters"], e["iters"]) and (r["status"] == 0).all()
+    assert np.abs(r["z"] - e["z"]).max() <= 1e-10 and np.abs(r["lam_g"] - e["lam_g"]).max() <= 1e-9 * np.abs(r["lam_g"]).max()
+    eu = oracle.solve(product_cfg(30, 1), x0, xs, obs)
+    assert 1e-3 < np.abs(eu["z"] - r["z"]).max() < 2.0                      # a different discretisation, the same manoeuvre
+    for b in range(3):
+        nlp = kkt_check.KinNlp(30, 0.1, x0[b], xs[b], obs[b], integrator="rk4")
+        c = kkt_check.certificate(nlp, e["z"][b], e["lam_g"][b], e["lam_x"][b])
+        assert c["stationarity"] <= 1e-6 * c["lam_scale"] and c["feas_g"] <= 2e-8 and c["compl"] <= 1e-3 and c["sign"] == 0.0, c
+        assert c["f"] == pytest.approx(e["obj"][b], rel=1e-11)
+    c3 = product_cfg(30, 3); c3.integrator = _abi.INT_RK4                  # three predicted obstacles through the <3> instantiation
+    x0, xs, _, traj = scenes.sample_c3(3, N=30, dt=0.1, seed=5)
+    r = oracle.solve(c3, x0, xs, traj); e = emu.solve(c3, x0, xs, traj)
+    assert np.array_equal(r["status"], e["status"]) and np.array_equal(r["iters"], e["iters"])
+    ok = r["status"] == 0
+    assert ok.any() and np.abs(r["z"][ok] - e["z"][ok]).max() <= 1e-10

@@ -136,8 +136,8 @@ def test_edge_cases_on_device(gpu_solver_factory, yaml_horizon3):
     with pytest.raises(MpcbError):         # CBF rows at the terminal node would need X_{N+1}: rejected (the dyn default has obs_terminal = 1)
         bad = default_config(model=_abi.MODEL_DYN, N=20, n_obs=1); bad.obs_mode = _abi.OBS_DCBF
         gpu_solver_factory(bad)
-    with pytest.raises(MpcbError):         # RK4 is named by BASELINE.json's north_star but is not the reference's integrator
-        bad = default_config(N=30, n_obs=1); bad.integrator = _abi.INT_RK4
+    with pytest.raises(MpcbError):         # RK4 exists for the kinematic model with keep-out / gamma = 1 rows only
+        bad = default_config(model=_abi.MODEL_DYN, N=30, n_obs=1); bad.integrator = _abi.INT_RK4
         gpu_solver_factory(bad)
     for gamma, model in ((1.5, _abi.MODEL_KIN), (0.0, _abi.MODEL_KIN), (0.8, _abi.MODEL_DYN)):
         with pytest.raises(MpcbError):     # gamma outside (0, 1]; general gamma for the dyn model (not implemented)
@@ -303,7 +303,8 @@ def test_drop_in_surface_with_the_shipped_yaml(oracle_mod):
     lbg, ubg, lbx, ubx = m.initialize_constraints(obs)
     solver = m.optimize_problem(ego_state=x0, ref_state=None, obstacle=obs)
     res = solver(x0=np.zeros((304, 1)), p=np.concatenate((x0, xs)), lbg=lbg, lbx=lbx, ubg=ubg, ubx=ubx)
-    ref = oracle_mod.solve(default_config(N=50, n_obs=1), x0.T, xs.T, obs[None])
+    c50 = default_config(N=50, n_obs=1); c50.second_start = 2            # what the drop-in classes configure (_mpc_base.py)
+    ref = oracle_mod.solve(c50, x0.T, xs.T, obs[None])
     assert solver.stats()["success"] and ref["status"][0] == 0
     assert res["x"].full().shape == (304, 1) and np.abs(res["x"].full()[:, 0] - ref["z"][0]).max() <= TOL_Z
     assert res["g"].full().shape == (303, 1)
@@ -528,6 +529,40 @@ def test_general_gamma_cbf_rows(gpu_solver_factory, oracle_mod, n_obs, gamma):
         nlp = kkt_check.KinNlp(30, 0.1, scenes.SHIPPED_X0, scenes.SHIPPED_XS, scenes.SHIPPED_OBS, obs_mode="dcbf", gamma=gamma)
         c = kkt_check.certificate(nlp, s["z"][0], s["lam_g"][0], s["lam_x"][0])
         assert s["status"][0] == 0 and c["stationarity"] <= 1e-6 * c["lam_scale"] and c["feas_g"] <= 2e-8 and c["sign"] == 0.0
+
+
+def test_rk4_shooting_rows_on_device(gpu_solver_factory, oracle_mod):
+    """cfg.integrator = MPCB_INT_RK4 (north_star's "per-shooting-node RK4 roll-out"; the reference itself integrates with explicit
+    Euler, kin.py:207): the RK4 kernel instantiations against the oracle (AD over four rhs evaluations) on C2 / C3 batches, the
+    independent certificate with RK4 rows, and the device closed loop, whose plant step follows the integrator."""
+    from oracle import kkt_check
+    cfg = default_config(N=30, n_obs=1); cfg.integrator = _abi.INT_RK4
+    x0, xs, obs = scenes.sample_c2(256, seed=91)
+    bs = gpu_solver_factory(cfg)
+    g = bs.solve_batch(x0, xs, obs, multipliers=True); r = oracle_mod.solve(cfg, x0, xs, obs)
+    both = agree(g, r, min_same_status=0.97)
+    assert both.sum() >= 230 and (g["iters"] == r["iters"])[both].mean() >= 0.9
+    for b in np.nonzero(g["status"] == 0)[0][:24]:
+        c = kkt_check.certificate(kkt_check.KinNlp(30, 0.1, x0[b], xs[b], obs[b], integrator="rk4"), g["z"][b], g["lam_g"][b], g["lam_x"][b])
+        assert c["stationarity"] <= 1e-6 * c["lam_scale"] and c["feas_g"] <= 2e-8 and c["compl"] <= 1e-3 and c["sign"] == 0.0, (b, c)
+    e = gpu_solver_factory(default_config(N=30, n_obs=1)).solve_batch(x0, xs, obs)
+    bb = (g["status"] == 0) & (e["status"] == 0)
+    assert 1e-3 < np.median(np.abs(g["z"] - e["z"])[bb].max(axis=1)) < 1.0              # another discretisation of the same manoeuvre
+    c3 = default_config(N=30, n_obs=3); c3.integrator = _abi.INT_RK4
+    y0, ys, _, traj = scenes.sample_c3(128, N=30, dt=0.1, seed=92)
+    agree(gpu_solver_factory(c3).solve_batch(y0, ys, traj), oracle_mod.solve(c3, y0, ys, traj), min_same_status=0.95)
+    # closed loop: x_{t+1} is the RK4 step of the plant with the applied control
+    cl = bs.closed_loop(x0[:32], xs[:32], obs[:32], steps=6)
+    X, Uh = cl["x_hist"], cl["u_hist"]
+
+    def f(x, u):
+        return np.stack([x[:, 3] * np.cos(x[:, 2]), x[:, 3] * np.sin(x[:, 2]), x[:, 3] * np.tan(u[:, 0]) / 2.6, u[:, 1]], axis=1)
+    for t in range(6):
+        x = X[:, t]; u = Uh[:, t]
+        k1 = f(x, u); k2 = f(x + 0.05 * k1, u); k3 = f(x + 0.05 * k2, u); k4 = f(x + 0.1 * k3, u)
+        fin = np.isfinite(u).all(axis=1)
+        assert np.abs(x + 0.1 / 6 * (k1 + 2 * k2 + 2 * k3 + k4) - X[:, t + 1])[fin].max() <= 1e-10
+    assert (cl["status"][:, 0] == g["status"][:32]).all()
 
 
 def test_closed_loop_on_device_dynamic_model(gpu_solver_factory):

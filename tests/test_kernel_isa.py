@@ -29,7 +29,7 @@ def shipped():
 def test_only_kernels_are_emitted(shipped):
     ks, non_kernels = shipped
     assert non_kernels == [], "out-of-line device functions in the shipped code object: %s" % non_kernels
-    assert len([k for k in ks if k.startswith("mpcb_kernel_")]) == 24          # 8 kin + 4 dyn first-pass, as many restoration-pass kernels
+    assert len([k for k in ks if k.startswith("mpcb_kernel_")]) == 30          # 8 + 3 (RK4) kin + 4 dyn first-pass kernels, as many restoration-pass kernels
 
 
 def test_solve_kernels_have_no_flat_instruction_and_one_wave_workgroups(shipped):
@@ -43,8 +43,9 @@ def test_solve_kernels_have_no_flat_instruction_and_one_wave_workgroups(shipped)
         assert k["instr"].get("ds_", 0) > 300 and k["instr"].get("global_", 0) >= 19, name
 
 
-ZERO_SCRATCH = ["mpcb_kernel_kin<0, false>", "mpcb_kernel_kin<1, false>", "mpcb_kernel_kin<3, false>", "mpcb_kernel_kin<1, true>",
-                "mpcb_kernel_dyn<1>", "mpcb_kernel_dyn<3>", "mpcb_kernel_kin_resto<0, false>", "mpcb_kernel_kin_resto<1, false>"]
+ZERO_SCRATCH = ["mpcb_kernel_kin<0, false, false>", "mpcb_kernel_kin<1, false, false>", "mpcb_kernel_kin<3, false, false>", "mpcb_kernel_kin<1, true, false>",
+                "mpcb_kernel_kin<0, false, true>", "mpcb_kernel_kin<1, false, true>", "mpcb_kernel_kin<3, false, true>",
+                "mpcb_kernel_dyn<1>", "mpcb_kernel_dyn<3>", "mpcb_kernel_kin_resto<0, false, false>", "mpcb_kernel_kin_resto<1, false, false>"]
 
 
 @pytest.mark.parametrize("name", ZERO_SCRATCH)
