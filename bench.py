@@ -83,13 +83,31 @@ def algorithmic_bytes_per_solve(nx, nz, n_obs_values, with_z0=True):
 
 
 def host_cores():
-    """Every core this process may run on (the CPU leg uses all host cores); MPCB_CPU_THREADS overrides."""
+    """The cores this process may actually use: its affinity mask, cut to the CPU quota of its control group when there is one (on the
+    one-GPU boxes the mask shows every core of the host, 256, while the container's share is 16: 256 OpenMP threads on 16 cores'
+    worth of quota ran the oracle three times SLOWER than 16 threads).  MPCB_CPU_THREADS overrides."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        cores = min(cores, max(1, int(round(quota))))
+    elif cores > 64 and not os.environ.get("MPCB_CPU_THREADS"):
+        cores = 16          # no quota visible but a whole host's mask: the documented CPU share of a one-GPU box
     if os.environ.get("MPCB_CPU_THREADS"):
-        cores = min(cores, int(os.environ["MPCB_CPU_THREADS"]))
+        cores = int(os.environ["MPCB_CPU_THREADS"])
     return max(1, cores)
 
 
@@ -101,7 +119,8 @@ def cpu_baseline(cfg, x0, xs, obs, min_seconds=1.5):
     native = oracle.use_native_build()
     cores = host_cores()
     n = min(len(x0), 2048)
-    oracle.solve(cfg, x0[:4 * cores], xs[:4 * cores], obs[:4 * cores], threads=cores, want_multipliers=False)   # untimed: starts the OpenMP team, first-touch of the per-thread arenas
+    w = min(len(x0), 4 * cores)
+    oracle.solve(cfg, x0[:w], xs[:w], obs[:w], threads=cores, want_multipliers=False)   # untimed: starts the OpenMP team, first-touch of the per-thread arenas
     t0 = time.perf_counter(); reps = 0; solved = 0
     while True:
         r = oracle.solve(cfg, x0[:n], xs[:n], obs[:n], threads=cores, want_multipliers=False)
@@ -115,7 +134,7 @@ def cpu_baseline(cfg, x0, xs, obs, min_seconds=1.5):
     lat_ms = 1e3 * (time.perf_counter() - t1) / m
     return {"value": solved / dt, "unit": "solves/s", "cores": cores, "kind": "port", "single_thread_ms_per_instance": lat_ms,
             "build": ("g++ %s -fopenmp, compiled on this host" % native) if native else "g++ -O2 -fopenmp (portable build; no compiler on this host)",
-            "threads": "every core of the process's affinity mask (%d)" % cores,
+            "threads": "affinity mask cut to the cgroup CPU quota (%d)" % cores,
             "sample": "%d x first %d instances of the step's batch, OpenMP over instances, %.1f s wall (%.0f core-s); latency: %d instances on one thread" % (reps, n, dt, dt * cores, m),
             "note": "own FP64 C++ restatement of the NLP + IPOPT-style solver; CasADi+IPOPT baseline unavailable (casadi not installed)"}
 
@@ -129,7 +148,8 @@ def cpu_baseline_closed_loop(cfg, x0, xs, obs, sim_steps, min_seconds=8.0):
     cores = host_cores()
     n = min(len(x0), 768); N = cfg.N
     xc = x0[:n].copy(); oc = obs[:n].copy(); z0 = np.zeros((n, 2 * N + 4 * (N + 1)))
-    oracle.solve(cfg, xc[:4 * cores], xs[:4 * cores], scenes.predict_obstacles(oc[:4 * cores], cfg.T, N), threads=cores, want_multipliers=False)   # untimed warm-up of the OpenMP team
+    w = min(n, 4 * cores)
+    oracle.solve(cfg, xc[:w], xs[:w], scenes.predict_obstacles(oc[:w], cfg.T, N), threads=cores, want_multipliers=False)   # untimed warm-up of the OpenMP team
     t0 = time.perf_counter(); solved = 0; done = 0
     for _ in range(sim_steps):
         r = oracle.solve(cfg, xc, xs[:n], scenes.predict_obstacles(oc, cfg.T, N), z0=z0, threads=cores, want_multipliers=False)
@@ -283,6 +303,9 @@ def main():
     ap.add_argument("--batches", type=int, default=5,
                     help="distinct synthetic batches resident in HBM, used round-robin by the steps (the launch time of a 4096-instance "
                          "batch moves +-15 %% with where its slowest instances fall in the dispatch order; one batch would report one draw)")
+    ap.add_argument("--second-start", type=int, default=None, choices=[0, 1, 2],
+                    help="cfg.second_start (default: what mpcb_default_config ships, 1): 0 = one attempt per instance (round-2 behaviour), 2 = second "
+                         "attempt after the first attempt's restoration phase")
     ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"],
                     help="shooting rows: explicit Euler (the reference's NLP, kin.py:207: the headline) or the RK4 instantiations (kinematic configurations)")
     ap.add_argument("--warm", action="store_true",
@@ -331,6 +354,8 @@ def main():
         workload = "C5: closed loop, %d scenes per GPU x 80 receding-horizon steps, kinematic bicycle + 3 moving obstacles re-predicted every step" % B
     if args.no_restoration:
         cfg.restoration = 0
+    if args.second_start is not None:
+        cfg.second_start = args.second_start
     if args.integrator == "rk4":
         cfg.integrator = _abi.INT_RK4
         workload += " [RK4 shooting rows]"
@@ -477,7 +502,7 @@ def main():
                        "status_histogram_rank0": {str(k): int(v) for k, v in enumerate(np.bincount(status, minlength=7))},
                        "iters_mean_solved": float(it_ok.mean()) if len(it_ok) else None, "iters_max": int(iters.max()),
                        "iters_share_of_unsolved": float(iters[status != 0].sum() / max(1, iters.sum())),
-                       "restoration": bool(cfg.restoration), "integrator": "rk4" if cfg.integrator == _abi.INT_RK4 else "euler",
+                       "restoration": bool(cfg.restoration), "second_start": int(cfg.second_start), "integrator": "rk4" if cfg.integrator == _abi.INT_RK4 else "euler",
                        "solver_handles": HN, "launch_lanes_per_handle": F, "launches_per_step": launches / args.steps, "tol": cfg.tol,
                        "collective": "RCCL all-gather of z per step inside libmpcbatch (mpcb_allgather), overlapped with the next steps' solves" if grp.active else "none",
                        "value_without_gather": (solved_all / dt_nogather_max) if dt_nogather else None,

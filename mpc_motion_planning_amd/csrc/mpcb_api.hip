@@ -28,29 +28,56 @@ namespace {
 constexpr double INF = std::numeric_limits<double>::infinity();
 thread_local std::string g_create_error;
 
+// MPCB_FUSED_SECOND (an experiment kept for re-measurement, off in the shipped build): with cfg.second_start = 1 both attempts of an instance
+// run in ONE launch — the wave whose first attempt failed starts over from z = 0 at once instead of in a second launch that can only
+// begin when the slowest first attempt of the batch has finished.  Measured on MI355X: C2 +2.5 %, one launch at a time +11 %, but C3 -9 %
+// and C4 -7 %: the loop around the inlined solve keeps its loop-invariant per-lane constants alive across both attempts (kin<3>: 200 -> 256
+// AGPRs + 124 B scratch, dyn<3>: 236 -> 256 + 452 B).  The shipped build launches the second attempt as a pass of its own.
+__device__ __forceinline__ bool mpcb_second_attempt_here(const MpcbKArgs& a, int b, int pass) {
+#ifndef MPCB_FUSED_SECOND
+  return false;
+#endif
+  if (pass != MPCB_PASS_FIRST || a.cfg.second_start != 1 || !a.cfg.init_rollout || !a.status) return false;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");          // the status lane 0 has just stored
+  const int st = __builtin_nontemporal_load(a.status + (size_t)b * a.st_stride);
+  return st != MPCB_ST_SOLVED && st != MPCB_ST_ACCEPTABLE && st != MPCB_ST_INFEASIBLE_X0;
+}
+
 template <int NOBS, bool GEN = false, bool RK4 = false>
 __global__ __launch_bounds__(64, MPCB_WAVES_PER_SIMD) void mpcb_kernel_kin(const MpcbKArgs a) {
   extern __shared__ __attribute__((aligned(16))) double mpcb_lds[];
-  mpcb_solve_kin<NOBS, GEN, false, RK4>(a, (int)blockIdx.x, mpcb_lds);
+  int pass = a.pass;
+#pragma clang loop unroll(disable)
+  for (;;) {
+    mpcb_solve_kin<NOBS, GEN, false, RK4>(a, (int)blockIdx.x, mpcb_lds, pass);
+    if (!mpcb_second_attempt_here(a, (int)blockIdx.x, pass)) break;
+    pass = MPCB_PASS_SECOND;
+  }
 }
 
 // restoration pass: main phase + restoration phase; a workgroup whose instance does not need it returns at once
 template <int NOBS, bool GEN = false, bool RK4 = false>
 __global__ __launch_bounds__(64, 1) void mpcb_kernel_kin_resto(const MpcbKArgs a) {
   extern __shared__ __attribute__((aligned(16))) double mpcb_lds[];
-  mpcb_solve_kin<NOBS, GEN, true, RK4>(a, (int)blockIdx.x, mpcb_lds);
+  mpcb_solve_kin<NOBS, GEN, true, RK4>(a, (int)blockIdx.x, mpcb_lds, MPCB_PASS_RESTO);
 }
 
 template <int NOBS>
 __global__ __launch_bounds__(64, MPCB_WAVES_PER_SIMD) void mpcb_kernel_dyn(const MpcbKArgs a) {
   extern __shared__ __attribute__((aligned(16))) double mpcb_lds[];
-  mpcb_solve_dyn<NOBS>(a, (int)blockIdx.x, mpcb_lds);
+  int pass = a.pass;
+#pragma clang loop unroll(disable)
+  for (;;) {
+    mpcb_solve_dyn<NOBS>(a, (int)blockIdx.x, mpcb_lds, pass);
+    if (!mpcb_second_attempt_here(a, (int)blockIdx.x, pass)) break;
+    pass = MPCB_PASS_SECOND;
+  }
 }
 
 template <int NOBS>
 __global__ __launch_bounds__(64, 1) void mpcb_kernel_dyn_resto(const MpcbKArgs a) {
   extern __shared__ __attribute__((aligned(16))) double mpcb_lds[];
-  mpcb_solve_dyn<NOBS, true>(a, (int)blockIdx.x, mpcb_lds);
+  mpcb_solve_dyn<NOBS, true>(a, (int)blockIdx.x, mpcb_lds, MPCB_PASS_RESTO);
 }
 
 // f(x,u) of the configured model: the reference's `mpc_solver.f` (kin.py:153-159, dyn.py:156-177); host and device
@@ -562,7 +589,11 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in, int lane_id = 0) {
   // (cfg.second_start = 1: the first attempt's restoration pass is skipped — its instances go straight to the second start)
   if (rc == MPCB_OK && h->cfg.restoration && !(second_pass(h->cfg) && h->cfg.second_start == 1)) rc = resto_pass();
   if (rc == MPCB_OK && second_pass(h->cfg)) {
+#ifdef MPCB_FUSED_SECOND
+    if (h->cfg.second_start != 1) rc = lean_pass(MPCB_PASS_SECOND);       // (second_start = 1: the second attempt ran inside the first launch)
+#else
     rc = lean_pass(MPCB_PASS_SECOND);
+#endif
     if (rc == MPCB_OK && h->cfg.restoration) rc = resto_pass();
   }
   if (rc != MPCB_OK) return rc;

@@ -59,6 +59,13 @@ struct MpcbKArgs {
 #define MPCB_SCHED_FENCE() ((void)0)
 #endif
 
+// MPCB_LATE_TRACE (diagnostic builds only, tools/sync_ab.sh): the trace pointer late-loaded as well — together with the late-loaded output
+// pointers this build of kin<8, GEN> returned NONDETERMINISTIC wrong statuses on the GPU
+#ifdef MPCB_LATE_TRACE
+#define MPCB_TRACE_ARGS(a) wv::late_args(a)
+#else
+#define MPCB_TRACE_ARGS(a) (&(a))
+#endif
 // internal statuses between the passes of a solve; never returned to the caller
 #define MPCB_ST_NEEDS_RESTO 7
 #define MPCB_PASS_FIRST 0
@@ -282,7 +289,11 @@ constexpr double DW_FIRST = 1e-4, DW_MIN = 1e-20, DW_MAX = 1e40, KW_MINUS = 1.0 
 // RK4 = the shooting rows use the Runge-Kutta step (cfg.integrator = MPCB_INT_RK4; keep-out / gamma = 1 rows only, never with GEN): the
 //   stage's B block becomes dense (the control enters x+, y+ and phi+ through both columns), four more Hessian pairs exist.
 template <int NOBS, bool GEN = false, bool RESTO = false, bool RK4 = false>
-MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
+MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a_in, const int b, double* lds, const int pass) {   // pass: MPCB_PASS_* (see MpcbKArgs::pass; a parameter of its own because one launch can run two passes of an instance)
+  // every kernel argument is read through a pointer the optimiser cannot see through (wv::late_args): the compiler then loads a field
+  // where the code needs it instead of preloading the whole 800-byte argument block into scalar registers at entry, most of which it
+  // has to spill into VGPR lanes again (kin<3>: 806 -> 582 v_readlane of SGPR reloads)
+  const MpcbKArgs& a = *wv::late_args(a_in);
   static_assert(!(GEN && RK4), "general-gamma CBF rows are written for the Euler step");
   using namespace mpcbk;
   constexpr int NX = 4, NA = 6, NW = 8, NOB = NOBS > 0 ? NOBS : 1, NEL = RESTO ? NOB : 1;
@@ -290,7 +301,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   const int N = c.N, lane = wv::lane(), k = lane;
   const int nz = a.nz, nobs = c.n_obs;
   if (RESTO && a.status[(size_t)b * a.st_stride] != MPCB_ST_NEEDS_RESTO) return;     // wave-uniform: this instance is done
-  if (!RESTO && a.pass == MPCB_PASS_SECOND) {          // second start: only instances whose first attempt (restoration included) did not succeed
+  if (!RESTO && pass == MPCB_PASS_SECOND) {          // second start: only instances whose first attempt (restoration included) did not succeed
     const int st1 = a.status[(size_t)b * a.st_stride];
     if (st1 == MPCB_ST_SOLVED || st1 == MPCB_ST_ACCEPTABLE || st1 == MPCB_ST_INFEASIBLE_X0) return;
     bool fin = true;                                    // non-finite inputs: the first attempt's verdict (at iteration 0) stands
@@ -301,14 +312,16 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   // attempt (cfg.second_start, only after a roll-out start; mpcb_api.hip launches its passes after the first attempt's): the
   // reference's own first-step start z = 0 (main_cbf_kin_c_sim.py:47-50), no roll-out.  A restoration pass continues whichever
   // attempt handed over (WK_START).
-  const bool zeros_start = RESTO ? (a.work && a.work[(size_t)b * mpcbk::WK_SIZE + mpcbk::WK_START] != 0.0) : a.pass == MPCB_PASS_SECOND;
+  const bool zeros_start = RESTO ? (a.work && a.work[(size_t)b * mpcbk::WK_SIZE + mpcbk::WK_START] != 0.0) : pass == MPCB_PASS_SECOND;
   const bool rollout = c.init_rollout && !zeros_start;
   constexpr bool OBL = NOBS > 3;                  // obstacle constants in LDS ([4 * j + q][lane]) instead of registers
   const Layout L = layout_kin(N, nz, RESTO, obs_in_lds(NOBS), GEN || RK4);
   const int ld = L.ld;
   double* ent = lds + L.ent;
   // step length of this lane's stage: cfg.T, or the stage's entry of the time grid (lanes past the last stage take its value)
-  const double T = a.tgrid ? a.tgrid[k < N ? k : N - 1] : c.T, il = 1.0 / c.veh_l;
+  double T_ = wv::uni(c.T);              // (a VALUE before the branch: from a ?: of two loads the compiler selects between a global and a constant-space ADDRESS and loads through FLAT)
+  if (a.tgrid) T_ = a.tgrid[k < N ? k : N - 1];
+  const double T = T_, il = 1.0 / c.veh_l;
 
   const bool isnode = k <= N, hasu = k < N, xnode = k >= 1 && k <= N, xcost = k >= 1 && k < N;
   const double* gx0 = a.x0 + (size_t)b * NX;
@@ -949,8 +962,8 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         const double e_sc = fmax(S_MAX, wv::uni(ss[1]) / fmax(1.0, n_vr)) / S_MAX;
         const double base = fmax(e_dual / e_sd, e_prim);
         err0 = fmax(base, (n_vr > 0 ? sv_hi : 0.0) / e_sc);                      // complementarity error at mu = 0
-        if (wv::late_args(a)->trace && b == wv::late_args(a)->trace_instance && lane == 0 && iters <= c.max_iter) {
-          double* t = wv::late_args(a)->trace + (size_t)iters * 8;
+        if (MPCB_TRACE_ARGS(a)->trace && b == MPCB_TRACE_ARGS(a)->trace_instance && lane == 0 && iters <= c.max_iter) {
+          double* t = MPCB_TRACE_ARGS(a)->trace + (size_t)iters * 8;
           t[0] = mu; t[1] = err0; t[2] = theta; t[3] = fval;
         }
         if (!(RESTO && rs)) {
@@ -1476,8 +1489,8 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         alpha = wv::uni(alpha * 0.5);
         if (alpha < a_min || alpha < 1e-16) break;
       }
-      if (wv::late_args(a)->trace && b == wv::late_args(a)->trace_instance && lane == 0) {
-        double* t = wv::late_args(a)->trace + (size_t)iters * 8;
+      if (MPCB_TRACE_ARGS(a)->trace && b == MPCB_TRACE_ARGS(a)->trace_instance && lane == 0) {
+        double* t = MPCB_TRACE_ARGS(a)->trace + (size_t)iters * 8;
         t[4] = a_pr; t[5] = accepted ? alpha : 0.0; t[6] = a_du; t[7] = dw;
 #if defined(MPCB_STAMPS) && !defined(MPCB_WAVE_EMU)
         MPCB_STAMP(t_e);
@@ -1490,7 +1503,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
         if (lane == 0 && a.work) {
           double* wk = a.work + (size_t)b * WK_SIZE;
           wk[WK_MU] = mu; wk[WK_THMAX] = theta_max; wk[WK_THMIN] = theta_min; wk[WK_ITERS] = (double)it_done; wk[WK_DW] = dw_last;
-          wk[WK_START] = a.pass == MPCB_PASS_SECOND ? 1.0 : 0.0;
+          wk[WK_START] = pass == MPCB_PASS_SECOND ? 1.0 : 0.0;
         }
       };
       if (!accepted) {
@@ -1582,7 +1595,11 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
   // ----- outputs (reference ordering), staged through LDS for coalesced stores ----------------------------------
   // the output pointers and sizes are read from the kernel arguments HERE (wv::late_args) instead of being held in scalar registers
   // through the whole solve: the kernels spill ~190 SGPRs into VGPR lanes, every reload is a v_readlane in the iteration loop
+#ifdef MPCB_NO_LATE_OUT
+  const MpcbKArgs& ao = a;
+#else
   const MpcbKArgs& ao = *wv::late_args(a);
+#endif
   // `ko` = k behind an optimisation barrier: the LDS addresses of the z staging are re-formed here instead of being kept
   // live (and spilled) from the identical expressions at kernel start — hipcc 7.2 mis-reloaded such a spilled address in the
   // dyn<3> build (lanes >= 1 wrote their X rows to zbuf[0..5]).
@@ -1604,7 +1621,7 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a, const int b, double* lds) {
     int it_prev = 0;
     if (ao.work) {
       double* wk = ao.work + (size_t)b * mpcbk::WK_SIZE;
-      const bool second_attempt = RESTO ? wk[mpcbk::WK_START] != 0.0 : ao.pass == MPCB_PASS_SECOND;
+      const bool second_attempt = RESTO ? wk[mpcbk::WK_START] != 0.0 : pass == MPCB_PASS_SECOND;
       if (second_attempt) it_prev = (int)wk[mpcbk::WK_ITPREV];
       else wk[mpcbk::WK_ITPREV] = (double)iters;       // (also at a hand-over: with cfg.second_start = 1 no restoration pass of the first attempt follows)
     }

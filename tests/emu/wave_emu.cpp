@@ -35,14 +35,14 @@ static void run_instance(const MpcbKArgs& a, int b) {
     th.emplace_back([&, l]() {
       wv::t_lane = l; wv::t_emu = &emu;
       const bool gen = !dyn && a.cfg.obs_mode == MPCB_OBS_DCBF && a.cfg.gamma < 1.0 - 1e-12 && NOBS > 0;   // as mpcb_api.hip dispatches
-      if (dyn && rp) mpcb_solve_dyn<NOBS, true>(a, b, lds.data());
-      else if (dyn) mpcb_solve_dyn<NOBS>(a, b, lds.data());
-      else if (gen && rp) mpcb_solve_kin<(NOBS > 0 ? NOBS : 1), true, true>(a, b, lds.data());
-      else if (gen) mpcb_solve_kin<(NOBS > 0 ? NOBS : 1), true>(a, b, lds.data());
-      else if (rk4 && rp) mpcb_solve_kin<(NOBS <= 3 ? NOBS : 3), false, true, true>(a, b, lds.data());
-      else if (rk4) mpcb_solve_kin<(NOBS <= 3 ? NOBS : 3), false, false, true>(a, b, lds.data());
-      else if (rp) mpcb_solve_kin<NOBS, false, true>(a, b, lds.data());
-      else mpcb_solve_kin<NOBS>(a, b, lds.data());
+      if (dyn && rp) mpcb_solve_dyn<NOBS, true>(a, b, lds.data(), a.pass);
+      else if (dyn) mpcb_solve_dyn<NOBS>(a, b, lds.data(), a.pass);
+      else if (gen && rp) mpcb_solve_kin<(NOBS > 0 ? NOBS : 1), true, true>(a, b, lds.data(), a.pass);
+      else if (gen) mpcb_solve_kin<(NOBS > 0 ? NOBS : 1), true>(a, b, lds.data(), a.pass);
+      else if (rk4 && rp) mpcb_solve_kin<(NOBS <= 3 ? NOBS : 3), false, true, true>(a, b, lds.data(), a.pass);
+      else if (rk4) mpcb_solve_kin<(NOBS <= 3 ? NOBS : 3), false, false, true>(a, b, lds.data(), a.pass);
+      else if (rp) mpcb_solve_kin<NOBS, false, true>(a, b, lds.data(), a.pass);
+      else mpcb_solve_kin<NOBS>(a, b, lds.data(), a.pass);
     });
   for (auto& t : th) t.join();
 }

@@ -507,7 +507,7 @@ def test_fuzzed_structures_against_oracle(gpu_solver_factory):
     import importlib.util
     spec = importlib.util.spec_from_file_location("fuzz_gpu_vs_oracle", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_gpu_vs_oracle.py"))
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
-    assert mod.run(cases=40, seed=11, verbose=False) == 0
+    assert mod.run(cases=40, seed=11, verbose=bool(os.environ.get("MPCB_FUZZ_VERBOSE"))) == 0
 
 
 @pytest.mark.parametrize("n_obs,gamma", [(1, 0.8), (3, 0.5), (5, 0.3)])

@@ -44,6 +44,9 @@ def one_case(rng, c):
         cfg.init_rollout = 0                     # model): both solvers fail there, in different ways
     desc = "case %d: %s N=%d n_obs=%d(%s) B=%d mode=%d gamma=%.2f term=%d tol=%g rollout=%d" % (
         c, "dyn" if dyn else "kin", N, n_obs, kind, B, cfg.obs_mode, cfg.gamma, cfg.obs_terminal, cfg.tol, cfg.init_rollout)
+    import os
+    if os.environ.get("MPCB_FUZZ_VERBOSE"):
+        print("  starting " + desc, flush=True)
     try:
         bs = BatchSolver(cfg)
     except Exception as e:                       # configurations the library refuses are refused by design; show them
