@@ -44,7 +44,7 @@ PARITY_NOTE = ("parity UNPINNED vs the reference's CasADi+IPOPT (not installed h
                "independent KKT certificate (oracle/kkt_check.py)")
 
 
-def measured_counters(workload):
+def measured_counters(workload, settings=None):
     """Counters of this workload from the rocprofv3 PMC passes of tools/profile_round.sh (separate passes, never mixed with tracing),
     kept in profiles/traffic.json: HBM bytes per solve launch (FETCH_SIZE / WRITE_SIZE, KiB units, 2x correction on FETCH_SIZE as
     MI355X_MICROARCH.md prescribes) and FP64 operations per solve launch (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64: wave instructions
@@ -54,6 +54,8 @@ def measured_counters(workload):
     try:
         t = json.load(open(p))
         hits = [e for e in (t if isinstance(t, list) else [t]) if e.get("workload_key") == workload.split(":")[0]]
+        if settings is not None:      # counters of a run with other solver settings say nothing about this one
+            hits = [e for e in hits if e.get("workload") == workload and all(e.get("settings", {}).get(k) == v for k, v in settings.items())]
         if hits:
             e = hits[-1]
             return {"bytes_per_launch": e.get("bytes_per_launch"), "fp64_flop_per_launch": e.get("fp64_flop_per_launch"),
@@ -303,9 +305,10 @@ def main():
     ap.add_argument("--batches", type=int, default=5,
                     help="distinct synthetic batches resident in HBM, used round-robin by the steps (the launch time of a 4096-instance "
                          "batch moves +-15 %% with where its slowest instances fall in the dispatch order; one batch would report one draw)")
-    ap.add_argument("--second-start", type=int, default=None, choices=[0, 1, 2],
-                    help="cfg.second_start (default: what mpcb_default_config ships, 1): 0 = one attempt per instance (round-2 behaviour), 2 = second "
-                         "attempt after the first attempt's restoration phase")
+    ap.add_argument("--second-start", type=int, default=None, choices=[0, 1, 2, 3],
+                    help="cfg.second_start (default: what mpcb_default_config ships, 3 = by the kind of start: 1 for a cold start, 2 with a start "
+                         "vector): 0 = one attempt per instance (round-2 behaviour), 1 = second attempt instead of the first attempt's restoration "
+                         "phase, 2 = after it")
     ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"],
                     help="shooting rows: explicit Euler (the reference's NLP, kin.py:207: the headline) or the RK4 instantiations (kinematic configurations)")
     ap.add_argument("--warm", action="store_true",
@@ -474,12 +477,12 @@ def main():
             ok_e += int((bs.solve_batch(x0, xs, obs)["status"] == 0).sum())
         dte = (time.perf_counter() - t1) / reps_e
         e2e = {"value": ok_e / reps_e / dte, "unit": "solves/s", "ms_per_call": 1e3 * dte,
-               "what": "mpcb_solve with host pointers, one call at a time: H2D of x0/xs/obs + both passes + D2H of z, obj, status, iters, kkt"}
+               "what": "mpcb_solve with host pointers, one call at a time: H2D of x0/xs/obs + all launches of the solve + D2H of z, obj, status, iters, kkt"}
 
     if rank == 0:
         launches = max(1, tm["launches"])
         kernel_ms = tm["total_ms"] / launches
-        inst_per_launch = B * args.steps / launches                                # a launch = one chunk of the batch on one lane (both passes)
+        inst_per_launch = B * args.steps / launches                                # a launch = one solve call on one lane (all its passes)
         with_z0 = d_z0 is not None
         bytes_solve = algorithmic_bytes_per_solve(nx, nz, int(obs[0].size), with_z0)
         abytes = bytes_solve * inst_per_launch
@@ -487,12 +490,14 @@ def main():
         it_ok = iters[status == 0]
         flop_iter = 147e3 if cfg.model == _abi.MODEL_DYN else 56e3                  # ~56 kflop (kin N=30) / ~147 kflop (dyn N=40) per iteration
         flops_model = flop_iter * iters_per_launch / B * inst_per_launch            # model flops of one launch
-        ctr = measured_counters(workload)
+        ctr = measured_counters(workload, {"second_start": int(cfg.second_start), "restoration": bool(cfg.restoration),
+                                           "integrator": "rk4" if cfg.integrator == _abi.INT_RK4 else "euler"})
         flops_ctr = (ctr["fp64_flop_per_launch"] / B * inst_per_launch) if ctr.get("fp64_flop_per_launch") else None
         traffic = (ctr["bytes_per_launch"] / B * inst_per_launch) if ctr.get("bytes_per_launch") else None
         flops_used = flops_ctr if flops_ctr else flops_model
         kk = ("dyn" if cfg.model == _abi.MODEL_DYN else "kin", 1 if cfg.n_obs <= 1 else 3)
-        kname = ("mpcb_kernel_%s<%d>" % kk) + ((" + mpcb_kernel_%s_resto<%d> (one solve = first pass + restoration pass, timed together)" % kk) if cfg.restoration else "")
+        kname = ("mpcb_kernel_%s<%d>" % kk) + ((" + mpcb_kernel_%s_resto<%d>" % kk) if cfg.restoration else "") + \
+            " (one solve = its launches on one lane, timed together: first attempt, second start, restoration pass)"
         out = {
             "metric": "mpc_solves_per_sec", "value": solved_all / dt_max, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,

@@ -142,10 +142,14 @@ typedef struct mpcb_config {
   int32_t  second_start;                 /* An instance whose solve from a roll-out start (init_rollout = 1) fails (no acceptable step, a run of
                                             tiny steps, max_iter, numerics) is solved once more from the reference's own first-step start z = 0
                                             (main_cbf_kin_c_sim.py:47-50; dynamic model: 0 except vx = x0's, the tyre model divides by vx).
-                                              1 (mpcb_default_config): INSTEAD of the first attempt's restoration phase — only the second attempt
-                                                enters the restoration phase; three launches per solve;
+                                              1: INSTEAD of the first attempt's restoration phase — only the second attempt enters the
+                                                restoration phase; three launches per solve.  Right for cold starts: a first attempt that
+                                                stalls in front of an obstacle is better restarted than restored;
                                               2: AFTER the first attempt's restoration phase — every instance one attempt solves stays solved,
-                                                bit for bit; four launches per solve (the drop-in classes use this);
+                                                bit for bit; four launches per solve.  Right for warm starts (a closed loop): restoring from
+                                                a good start vector beats starting over;
+                                              3 (mpcb_default_config): 1 for a solve without a start vector (z0 = NULL), 2 for a solve with one
+                                                (every step of mpcb_closed_loop, the drop-in classes);
                                               0: one attempt, as IPOPT.
                                             `iters` counts both attempts, each has max_iter of its own.  Without a roll-out (init_rollout = 0:
                                             the start taken as given, IPOPT's behaviour) there is one attempt, whatever this field says. */

@@ -397,7 +397,7 @@ int check_cfg(mpcb_handle* h, const mpcb_config* c) {
   if (c->integrator == MPCB_INT_RK4 && (c->model != MPCB_MODEL_KIN || c->n_obs > 3 || (c->obs_mode == MPCB_OBS_DCBF && c->gamma < 1.0 - 1e-12)))
     return fail(h, MPCB_E_UNSUPPORTED, "MPCB_INT_RK4 is built for the kinematic model with up to 3 obstacles and keep-out / gamma = 1 rows");
   if (c->restoration != 0 && c->restoration != 1) return fail(h, MPCB_E_INVALID, "restoration must be 0 or 1");
-  if (c->second_start < 0 || c->second_start > 2) return fail(h, MPCB_E_INVALID, "second_start must be 0, 1 or 2");
+  if (c->second_start < 0 || c->second_start > 3) return fail(h, MPCB_E_INVALID, "second_start must be 0, 1, 2 or 3");
   if (std::isfinite(c->x_lo[0]) || std::isfinite(c->x_hi[0]) || std::isfinite(c->x_lo[2]) || std::isfinite(c->x_hi[2]))
     return fail(h, MPCB_E_UNSUPPORTED, "state boxes are supported on y, vx (and vy for the dynamic model) (kin.py:97-105, dyn.py:97-110)");
   if (c->model == MPCB_MODEL_KIN) {
@@ -489,6 +489,9 @@ int ensure_lanes(mpcb_handle* h, int k) {
 
 bool second_pass(const mpcb_config& c) { return c.second_start != 0 && c.init_rollout != 0; }      // a second start exists only after a roll-out start
 bool multi_pass(const mpcb_config& c) { return c.restoration != 0 || second_pass(c); }
+// cfg.second_start = 3: the order of the passes follows the kind of start — a cold start (z0 = NULL) behaves as 1, a solve with a start
+// vector (a warm start, every step of a closed loop) as 2
+int second_mode(const mpcb_config& c, const void* z0) { return c.second_start == 3 ? (z0 ? 2 : 1) : c.second_start; }
 
 // both passes of one solve on lane `lane_id` (0 = the handle's own stream)
 int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in, int lane_id = 0) {
@@ -585,12 +588,13 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in, int lane_id = 0) {
   // first attempt from the caller's start, its restoration pass; with a second start (cfg.second_start after a roll-out start) the
   // lean kernel once more over the same grid, where only the instances whose first attempt did not succeed run from z = 0, and the
   // restoration pass of that attempt
+  const int ss = second_mode(h->cfg, a.z0);
   rc = lean_pass(MPCB_PASS_FIRST);
-  // (cfg.second_start = 1: the first attempt's restoration pass is skipped — its instances go straight to the second start)
-  if (rc == MPCB_OK && h->cfg.restoration && !(second_pass(h->cfg) && h->cfg.second_start == 1)) rc = resto_pass();
+  // (second start of kind 1: the first attempt's restoration pass is skipped — its instances go straight to the second start)
+  if (rc == MPCB_OK && h->cfg.restoration && !(second_pass(h->cfg) && ss == 1)) rc = resto_pass();
   if (rc == MPCB_OK && second_pass(h->cfg)) {
 #ifdef MPCB_FUSED_SECOND
-    if (h->cfg.second_start != 1) rc = lean_pass(MPCB_PASS_SECOND);       // (second_start = 1: the second attempt ran inside the first launch)
+    if (ss != 1) rc = lean_pass(MPCB_PASS_SECOND);       // (kind 1: the second attempt ran inside the first launch)
 #else
     rc = lean_pass(MPCB_PASS_SECOND);
 #endif
@@ -692,7 +696,7 @@ int mpcb_default_config(mpcb_config* cfg, int32_t model, int32_t N, double T) {
   c.dual_inf_tol = 1.0; c.constr_viol_tol = 1e-4; c.compl_inf_tol = 1e-4;
   c.acceptable_tol = 1e-8; c.acceptable_obj_change_tol = 1e-6; c.acceptable_iter = 15;
   c.acceptable_constr_viol_tol = 1e-2; c.acceptable_dual_inf_tol = 1e10; c.acceptable_compl_inf_tol = 1e-2;
-  c.second_start = 1;
+  c.second_start = 3;
   *cfg = c;
   return MPCB_OK;
 }

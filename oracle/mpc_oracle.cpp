@@ -1310,7 +1310,9 @@ int mpco_solve(const mpcb_config* cfg, int32_t B, const double* x0, const double
     static thread_local void* arena = nullptr;
     if (!arena) arena = ::operator new(sizeof(Solver));
     Solver* s = new (arena) Solver(*cfg);
-    s->defer_restoration = cfg->second_start == 1 && cfg->init_rollout != 0;
+    // cfg.second_start = 3: a cold start (z0 = NULL) behaves as 1, a solve with a start vector as 2
+    const int ss = cfg->second_start == 3 ? (z0 ? 2 : 1) : cfg->second_start;
+    s->defer_restoration = ss == 1 && cfg->init_rollout != 0;
     bool ok = s->init(x0 + (size_t)b * nx, xs + (size_t)b * nx, obs ? obs + b * obs_stride : nullptr, obs_kind,
                       z0 ? z0 + (size_t)b * nz : nullptr, tgrid);
     if (ok) s->solve(); else s->eval_point();

@@ -70,7 +70,8 @@ extern "C" int mpcb_emu_solve(const mpcb_config* cfg, int32_t B, const double* x
   for (int q = 0; q < 4; ++q) {
     const int pass = order[q];
     if ((q >= 2 && !second) || (pass == MPCB_PASS_RESTO && !cfg->restoration)) continue;
-    if (q == 1 && second && cfg->second_start == 1) continue;      // second start instead of the first attempt's restoration
+    const int ss = cfg->second_start == 3 ? (z0 ? 2 : 1) : cfg->second_start;   // 3: by the kind of start, as mpcb_api.hip
+    if (q == 1 && second && ss == 1) continue;      // second start instead of the first attempt's restoration
     a.pass = pass;
     for (int b = 0; b < B; ++b) {
       if (pass == MPCB_PASS_SECOND && (status[b] == MPCB_ST_SOLVED || status[b] == MPCB_ST_ACCEPTABLE || status[b] == MPCB_ST_INFEASIBLE_X0)) continue;

@@ -96,3 +96,19 @@ def test_missing_rccl_is_an_error_code_not_a_crash():
 
 def test_inflight_argument_checks_need_no_device():
     assert _lib.lib().mpcb_set_inflight(None, 2) == _abi.E_INVALID
+
+
+def test_integration_stub_declares_the_same_struct():
+    """The ctypes structure INTEGRATION.md §B shows a maintainer is the one the library expects (same fields, same order, same size)."""
+    text = open(os.path.join(os.path.dirname(__file__), "..", "INTEGRATION.md")).read()
+    m = re.search(r"class _Cfg\(C\.Structure\):.*?\n(?=\n)", text, re.S)
+    assert m, "stub not found"
+    ns = {"C": C}
+    exec(m.group(0), ns)
+    stub = ns["_Cfg"]
+    assert [f[0] for f in stub._fields_] == [f[0] for f in _abi.MpcbConfig._fields_]
+    assert C.sizeof(stub) == C.sizeof(_abi.MpcbConfig)
+    cfg = stub()
+    raw = C.CDLL(_lib.lib()._name)                       # an untyped binding, as the stub's own C.CDLL(...)
+    assert raw.mpcb_default_config(C.byref(cfg), 0, C.c_int32(30), C.c_double(0.1)) == 0 and cfg.struct_size == C.sizeof(stub)
+    assert cfg.second_start == 3 and cfg.acceptable_iter == 15 and cfg.acceptable_tol == 1e-8

@@ -650,6 +650,22 @@ def test_launch_lanes_of_one_handle_give_the_same_results(gpu_solver_factory):
     assert np.array_equal(h.solve_batch(x1, xs, ob1)["z"], r[1]["z"])
 
 
+def test_second_start_follows_the_kind_of_start_on_device(gpu_solver_factory, oracle_mod):
+    """cfg.second_start = 3 (the shipped default): cold start = kind 1, with a start vector = kind 2 (include/mpcbatch.h) — bit for bit
+    the explicit settings on the device, and the oracle's statuses."""
+    x0, xs, obs = scenes.sample_c2(256, seed=4)
+    auto = default_config(N=30, n_obs=1); assert auto.second_start == 3
+    one = auto.copy(); one.second_start = 1
+    two = auto.copy(); two.second_start = 2
+    a = gpu_solver_factory(auto).solve_batch(x0, xs, obs); b = gpu_solver_factory(one).solve_batch(x0, xs, obs)
+    assert np.array_equal(a["z"], b["z"]) and np.array_equal(a["status"], b["status"]) and np.array_equal(a["iters"], b["iters"])
+    z0 = np.zeros_like(a["z"]); z0[:, 0:60:2] = 0.01
+    c = gpu_solver_factory(auto).solve_batch(x0, xs, obs, z0=z0); d = gpu_solver_factory(two).solve_batch(x0, xs, obs, z0=z0)
+    assert np.array_equal(c["z"], d["z"]) and np.array_equal(c["status"], d["status"]) and np.array_equal(c["iters"], d["iters"])
+    ref = oracle_mod.solve(auto, x0, xs, obs, z0=z0, want_multipliers=False)
+    assert (ref["status"] == c["status"]).mean() >= 0.98 and (ref["iters"] == c["iters"]).mean() >= 0.95
+
+
 def test_multi_gpu_paths_inside_the_library(gpu_solver_factory):
     """include/mpcbatch.h "multi-GPU": a device group of this process (mpcb_set_devices -> ncclCommInitAll; shards, solves,
     all-gathers z) and the one-process-per-GPU group (mpcb_comm_init_rank) on the devices that are visible — on a one-GPU box

@@ -17,7 +17,7 @@ TOL_Z = 1e-6       # trajectory tolerance used throughout (north_star: <= 1e-4 v
 
 def product_cfg(N=30, n_obs=1):
     c = oracle.default_config(N=N, n_obs=n_obs)
-    c.init_rollout = 1; c.mu_init = 10.0; c.second_start = 1        # the settings mpcb_default_config ships
+    c.init_rollout = 1; c.mu_init = 10.0; c.second_start = 3        # the settings mpcb_default_config ships
     return c
 
 
@@ -156,7 +156,7 @@ def test_restoration_phase_rescues_and_classifies():
     # the second start (cfg.second_start, what mpcb_default_config ships): an instance whose attempt from the roll-out start fails
     # is solved once more from z = 0, the reference's own first-step start.  Nothing the first attempt solves changes (bit for bit),
     # nearly all of the "locally infeasible" instances turn out to be solvable, iterations of both attempts are counted
-    d = oracle.solve(product_cfg(), x0, xs, obs, want_multipliers=False)      # second_start = 1: INSTEAD of the first attempt's restoration phase
+    d = oracle.solve(product_cfg(), x0, xs, obs, want_multipliers=False)      # second_start = 3 on a cold start = 1: INSTEAD of the first attempt's restoration phase
     ok_d = d["status"] == 0
     assert np.array_equal(d["z"][ident], b["z"][ident]) and np.array_equal(d["iters"][ident], b["iters"][ident])   # instances that never leave the main phase
     assert ok_d.sum() >= 0.98 * len(x0) and (ok_d & ~ok_b).sum() >= 0.9 * (~ok_b).sum() and d["iters"].max() <= 200
@@ -205,3 +205,18 @@ def test_dynamic_bicycle_golden_and_certificate():
     ci = oracle.default_config(model=_abi.MODEL_DYN, N=40, n_obs=1)
     ri = oracle.solve(ci, scenes.DYN_X0[None], scenes.DYN_XS[None], scenes.DYN_OBS[None])
     assert ri["status"][0] != 0 or np.abs(ri["z"] - G["D_z"]).max() <= 1e-4
+
+
+def test_second_start_follows_the_kind_of_start():
+    """cfg.second_start = 3 (what mpcb_default_config ships): a cold start (z0 = None) behaves as 1 — second start INSTEAD of the first
+    attempt's restoration phase —, a solve with a start vector as 2 — AFTER it (include/mpcbatch.h)."""
+    x0, xs, obs = scenes.sample_c2(96, seed=4)
+    auto, one, two = product_cfg(), product_cfg(), product_cfg()
+    one.second_start = 1; two.second_start = 2
+    a = oracle.solve(auto, x0, xs, obs, want_multipliers=False); b = oracle.solve(one, x0, xs, obs, want_multipliers=False)
+    assert np.array_equal(a["z"], b["z"]) and np.array_equal(a["status"], b["status"]) and np.array_equal(a["iters"], b["iters"])
+    z0 = np.zeros_like(a["z"]); z0[:, 0:60:2] = 0.01                       # a start vector: slight steering, states rolled out from x0
+    c = oracle.solve(auto, x0, xs, obs, z0=z0, want_multipliers=False); d = oracle.solve(two, x0, xs, obs, z0=z0, want_multipliers=False)
+    e = oracle.solve(one, x0, xs, obs, z0=z0, want_multipliers=False)
+    assert np.array_equal(c["z"], d["z"]) and np.array_equal(c["status"], d["status"]) and np.array_equal(c["iters"], d["iters"])
+    assert not np.array_equal(c["iters"], e["iters"])                       # (the two orders do differ on this batch)

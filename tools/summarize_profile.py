@@ -15,7 +15,13 @@ except Exception:
 if bench:
     lines.append("# bench line of the same command: %s %s, %.3f ms/step, kernel avg via HIP events %.3f ms" % (
         bench.get("value"), bench.get("unit"), bench.get("ms_per_step", float("nan")), bench.get("roofline", {}).get("kernel_ms_avg", float("nan"))))
-# one solve = two launches since round 2 (first pass + restoration pass): every kernel gets its own block, taken from its last dispatch
+# one solve = several launches (round 3: first attempt, second start, restoration pass — 1..4 by cfg.restoration / cfg.second_start):
+# every launch of the LAST solve of the run gets its own block; sums over them are "per solve launch" figures
+cfgb = bench.get("config", {})
+ss, resto = int(cfgb.get("second_start", 0) or 0), bool(cfgb.get("restoration", True))
+if ss == 3:
+    ss = 2 if "warm" in cfgb.get("workload", "").lower() else 1        # by the kind of start (include/mpcbatch.h)
+n_launch = 1 + (1 if ss else 0) + ((2 if ss == 2 else 1) if resto else 0)
 allv = {}
 for g in "abcde":
     files = glob.glob(os.path.join(out, "pmc" + g, "**", "*counter_collection.csv"), recursive=True)
@@ -23,15 +29,13 @@ for g in "abcde":
         continue
     rows = list(csv.DictReader(open(files[0])))
     rows = [r for r in rows if "mpcb_kernel" in r["Kernel_Name"]]
-    names = sorted(set(r["Kernel_Name"] for r in rows), key=lambda n: ("resto" in n, n))
-    for name in names:
-        mine = [r for r in rows if r["Kernel_Name"] == name]
-        last = max(int(r["Dispatch_Id"]) for r in mine)
-        sel = [r for r in mine if int(r["Dispatch_Id"]) == last]
+    ids = sorted(set(int(r["Dispatch_Id"]) for r in rows))[-n_launch:]
+    for pos, did in enumerate(ids):
+        sel = [r for r in rows if int(r["Dispatch_Id"]) == did]
         waves = int(sel[0]["Grid_Size"]) // int(sel[0]["Workgroup_Size"])
-        short = name.split("::")[-1]
+        short = "launch %d of %d: %s" % (pos + 1, len(ids), sel[0]["Kernel_Name"].split("::")[-1])
         vals = allv.setdefault(short, {})
-        lines.append("pass pmc%s: kernel %s  grid %s wg %s LDS %s scratch %s VGPR %s AGPR %s SGPR %s (last dispatch, whole grid | per launched wave)" % (
+        lines.append("pass pmc%s: %s  grid %s wg %s LDS %s scratch %s VGPR %s AGPR %s SGPR %s (whole grid | per launched wave)" % (
             g, short, sel[0]["Grid_Size"], sel[0]["Workgroup_Size"], sel[0]["LDS_Block_Size"],
             sel[0]["Scratch_Size"], sel[0]["VGPR_Count"], sel[0]["Accum_VGPR_Count"], sel[0]["SGPR_Count"]))
         for r in sorted(sel, key=lambda r: r["Counter_Name"]):
@@ -58,14 +62,15 @@ fp64 = sum(64.0 * (v.get("SQ_INSTS_VALU_ADD_F64", 0.0) + v.get("SQ_INSTS_VALU_MU
            for v in allv.values())
 if fp64:
     lines.append("")
-    lines.append("FP64 operations per solve launch (wave instructions x 64 lanes, FMA counted twice; both passes): %.4g flop" % fp64)
+    lines.append("FP64 operations per solve launch (wave instructions x 64 lanes, FMA counted twice; all launches of the solve): %.4g flop" % fp64)
 if bench and (tot_f or tot_w):
     # measured HBM bytes per solve (both launches), corrected as the guide prescribes; bench.py reports it as roofline.traffic (offline)
     wl = bench.get("config", {}).get("workload", "")
-    first = next((v for k, v in allv.items() if "resto" not in k and v.get("SQ_WAVE_CYCLES")), {})
+    first = next((v for k, v in allv.items() if k.startswith("launch 1 ") and v.get("SQ_WAVE_CYCLES")), {})
     wc = first.get("SQ_WAVE_CYCLES", 0.0)
     json.dump({"workload_key": wl.split(":")[0], "workload": wl, "round": sys.argv[2] if len(sys.argv) > 2 else None, "fetch_kib": tot_f, "write_kib": tot_w,
-               "bytes_per_launch": (2 * tot_f + tot_w) * 1024.0, "fp64_flop_per_launch": fp64 or None,
+               "bytes_per_launch": (2 * tot_f + tot_w) * 1024.0, "fp64_flop_per_launch": fp64 or None, "launches_per_solve": n_launch,
+               "settings": {"second_start": cfgb.get("second_start"), "restoration": cfgb.get("restoration"), "integrator": cfgb.get("integrator")},
                "valu_busy": (first.get("SQ_ACTIVE_INST_VALU", 0.0) / wc) if wc else None, "wait_any": (first.get("SQ_WAIT_ANY", 0.0) / wc) if wc else None},
               open(os.path.join(out, "traffic.json"), "w"))
 open(os.path.join(out, "pmc.txt"), "w").write("\n".join(lines) + "\n")
