@@ -78,6 +78,23 @@ def parity_evidence():
     return None
 
 
+def kernel_launches_per_solve(cfg, with_z0):
+    """Kernel launches behind one mpcb_solve_device call, as mpcb_api.hip's launch_solve orders them (used by tools/summarize_profile.py to
+    add up the counters of one solve): first attempt, [its restoration pass], [second start — none where the kernel runs it inside the first
+    launch: kin<0>, kin<1> with a second start of kind 1], [restoration pass]."""
+    from mpc_motion_planning_amd import _abi
+    second = bool(cfg.second_start) and bool(cfg.init_rollout)
+    kind = (2 if with_z0 else 1) if cfg.second_start == 3 else int(cfg.second_start)
+    gen = cfg.model == _abi.MODEL_KIN and cfg.obs_mode == _abi.OBS_DCBF and cfg.gamma < 1.0 - 1e-12 and cfg.n_obs > 0
+    fused = second and kind == 1 and cfg.model == _abi.MODEL_KIN and cfg.n_obs <= 1 and not gen and cfg.integrator != _abi.INT_RK4
+    n = 1
+    if cfg.restoration and not (second and kind == 1):
+        n += 1
+    if second:
+        n += (0 if fused else 1) + (1 if cfg.restoration else 0)
+    return n
+
+
 def algorithmic_bytes_per_solve(nx, nz, n_obs_values, with_z0=True):
     # SURVEY.md §8(d): 8*(2*nx + nz_in + obs_in + nz_out) + 16   (status i32 + iters i32 + obj f64).  Without a start vector
     # (z0 = NULL: the cold start of main_cbf_kin_c_sim.py:47-50) the nz_in term is not compulsory: nothing is read.
@@ -508,6 +525,7 @@ def main():
                        "iters_mean_solved": float(it_ok.mean()) if len(it_ok) else None, "iters_max": int(iters.max()),
                        "iters_share_of_unsolved": float(iters[status != 0].sum() / max(1, iters.sum())),
                        "restoration": bool(cfg.restoration), "second_start": int(cfg.second_start), "integrator": "rk4" if cfg.integrator == _abi.INT_RK4 else "euler",
+                       "kernel_launches_per_solve": kernel_launches_per_solve(cfg, d_z0 is not None),
                        "solver_handles": HN, "launch_lanes_per_handle": F, "launches_per_step": launches / args.steps, "tol": cfg.tol,
                        "collective": "RCCL all-gather of z per step inside libmpcbatch (mpcb_allgather), overlapped with the next steps' solves" if grp.active else "none",
                        "value_without_gather": (solved_all / dt_nogather_max) if dt_nogather else None,

@@ -28,16 +28,22 @@ namespace {
 constexpr double INF = std::numeric_limits<double>::infinity();
 thread_local std::string g_create_error;
 
-// MPCB_FUSED_SECOND (an experiment kept for re-measurement, off in the shipped build): with cfg.second_start = 1 both attempts of an instance
-// run in ONE launch — the wave whose first attempt failed starts over from z = 0 at once instead of in a second launch that can only
-// begin when the slowest first attempt of the batch has finished.  Measured on MI355X: C2 +2.5 %, one launch at a time +11 %, but C3 -9 %
-// and C4 -7 %: the loop around the inlined solve keeps its loop-invariant per-lane constants alive across both attempts (kin<3>: 200 -> 256
-// AGPRs + 124 B scratch, dyn<3>: 236 -> 256 + 452 B).  The shipped build launches the second attempt as a pass of its own.
-__device__ __forceinline__ bool mpcb_second_attempt_here(const MpcbKArgs& a, int b, int pass) {
-#ifndef MPCB_FUSED_SECOND
-  return false;
+// Second attempt inside the first launch (second start of kind 1, the cold-start batches): the wave whose first attempt failed starts
+// over from z = 0 at once instead of in a second launch that can only begin when the slowest first attempt of the batch has finished.
+// Only the instantiations with registers to spare do this (kin<0>, kin<1>: +17 AGPRs; measured C2 +2.5 % with six lanes, +11 % with one
+// launch at a time): the loop around the inlined solve keeps loop-invariant per-lane values alive across both attempts, which costs
+// kin<3> 200 -> 256 AGPRs + 124 B of scratch (C3 -9 %) and dyn<3> 236 -> 256 + 452 B (C4 -7 %).  Those launch the second attempt as a
+// pass of its own (launch_solve).  -DMPCB_NO_FUSED_SECOND: no instantiation fuses (A/B builds).
+#ifdef MPCB_NO_FUSED_SECOND
+template <int NOBS, bool GEN, bool RK4> constexpr bool mpcb_kin_fuses = false;
+#else
+template <int NOBS, bool GEN, bool RK4> constexpr bool mpcb_kin_fuses = NOBS <= 1 && !GEN && !RK4;
 #endif
-  if (pass != MPCB_PASS_FIRST || a.cfg.second_start != 1 || !a.cfg.init_rollout || !a.status) return false;
+__host__ __device__ inline bool mpcb_second_kind1(const mpcb_config& c, const void* z0) {   // cfg.second_start = 3: by the kind of start
+  return c.init_rollout && (c.second_start == 1 || (c.second_start == 3 && !z0));
+}
+__device__ __forceinline__ bool mpcb_second_attempt_here(const MpcbKArgs& a, int b, int pass) {
+  if (pass != MPCB_PASS_FIRST || !mpcb_second_kind1(a.cfg, a.z0) || !a.status) return false;
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");          // the status lane 0 has just stored
   const int st = __builtin_nontemporal_load(a.status + (size_t)b * a.st_stride);
   return st != MPCB_ST_SOLVED && st != MPCB_ST_ACCEPTABLE && st != MPCB_ST_INFEASIBLE_X0;
@@ -46,12 +52,16 @@ __device__ __forceinline__ bool mpcb_second_attempt_here(const MpcbKArgs& a, int
 template <int NOBS, bool GEN = false, bool RK4 = false>
 __global__ __launch_bounds__(64, MPCB_WAVES_PER_SIMD) void mpcb_kernel_kin(const MpcbKArgs a) {
   extern __shared__ __attribute__((aligned(16))) double mpcb_lds[];
-  int pass = a.pass;
+  if constexpr (mpcb_kin_fuses<NOBS, GEN, RK4>) {
+    int pass = a.pass;
 #pragma clang loop unroll(disable)
-  for (;;) {
-    mpcb_solve_kin<NOBS, GEN, false, RK4>(a, (int)blockIdx.x, mpcb_lds, pass);
-    if (!mpcb_second_attempt_here(a, (int)blockIdx.x, pass)) break;
-    pass = MPCB_PASS_SECOND;
+    for (;;) {
+      mpcb_solve_kin<NOBS, GEN, false, RK4>(a, (int)blockIdx.x, mpcb_lds, pass);
+      if (!mpcb_second_attempt_here(a, (int)blockIdx.x, pass)) break;
+      pass = MPCB_PASS_SECOND;
+    }
+  } else {
+    mpcb_solve_kin<NOBS, GEN, false, RK4>(a, (int)blockIdx.x, mpcb_lds, a.pass);
   }
 }
 
@@ -65,13 +75,7 @@ __global__ __launch_bounds__(64, 1) void mpcb_kernel_kin_resto(const MpcbKArgs a
 template <int NOBS>
 __global__ __launch_bounds__(64, MPCB_WAVES_PER_SIMD) void mpcb_kernel_dyn(const MpcbKArgs a) {
   extern __shared__ __attribute__((aligned(16))) double mpcb_lds[];
-  int pass = a.pass;
-#pragma clang loop unroll(disable)
-  for (;;) {
-    mpcb_solve_dyn<NOBS>(a, (int)blockIdx.x, mpcb_lds, pass);
-    if (!mpcb_second_attempt_here(a, (int)blockIdx.x, pass)) break;
-    pass = MPCB_PASS_SECOND;
-  }
+  mpcb_solve_dyn<NOBS>(a, (int)blockIdx.x, mpcb_lds, a.pass);
 }
 
 template <int NOBS>
@@ -593,11 +597,10 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in, int lane_id = 0) {
   // (second start of kind 1: the first attempt's restoration pass is skipped — its instances go straight to the second start)
   if (rc == MPCB_OK && h->cfg.restoration && !(second_pass(h->cfg) && ss == 1)) rc = resto_pass();
   if (rc == MPCB_OK && second_pass(h->cfg)) {
-#ifdef MPCB_FUSED_SECOND
-    if (ss != 1) rc = lean_pass(MPCB_PASS_SECOND);       // (kind 1: the second attempt ran inside the first launch)
-#else
-    rc = lean_pass(MPCB_PASS_SECOND);
-#endif
+    // (kind 1 on an instantiation that fuses: the second attempt ran inside the first launch)
+    const bool fused = ss == 1 && h->cfg.model == MPCB_MODEL_KIN && !is_gen(h->cfg) && !is_rk4(h->cfg) &&
+                       ((n == 0 && mpcb_kin_fuses<0, false, false>) || (n == 1 && mpcb_kin_fuses<1, false, false>));
+    if (!fused) rc = lean_pass(MPCB_PASS_SECOND);
     if (rc == MPCB_OK && h->cfg.restoration) rc = resto_pass();
   }
   if (rc != MPCB_OK) return rc;

@@ -298,7 +298,8 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a_in, const int b, double* lds, 
   using namespace mpcbk;
   constexpr int NX = 4, NA = 6, NW = 8, NOB = NOBS > 0 ? NOBS : 1, NEL = RESTO ? NOB : 1;
   const mpcb_config& c = a.cfg;
-  const int N = c.N, lane = wv::lane(), k = lane;
+  // (the lane index opaque: nothing derived from it is hoisted out of the attempt loop of the fusing kernels and kept alive across attempts)
+  const int N = c.N, lane = wv::opaque(wv::lane()), k = lane;
   const int nz = a.nz, nobs = c.n_obs;
   if (RESTO && a.status[(size_t)b * a.st_stride] != MPCB_ST_NEEDS_RESTO) return;     // wave-uniform: this instance is done
   if (!RESTO && pass == MPCB_PASS_SECOND) {          // second start: only instances whose first attempt (restoration included) did not succeed

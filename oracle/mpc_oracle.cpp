@@ -883,9 +883,100 @@ struct Solver {
     return dphi;
   }
 
-  // IPOPT's filter line search (Waechter-Biegler Alg. A, steps A-5) without second-order correction.
-  // Returns the accepted alpha, or 0 when alpha fell under alpha_min.
-  double line_search(double a_max, double mu_, double dphi, bool& armijo_type) {
+  // residuals of the constraints at the trial point  w + alpha d  (d = the direction arrays as they stand): shooting defects and
+  // c(w) - s - (p - n) of the general rows; boxes have none.  Used by the second-order correction only.
+  void trial_residuals(double alpha, double dfc_t[NODES][NXM], double rR_t[NODES][NU], double rO_t[NODES][NOBM]) {
+    static thread_local double Xt[NODES][NXM], Ut[NODES][NU];
+    for (int k = 0; k <= N; ++k) {
+      for (int i = 0; i < nx; ++i) Xt[k][i] = X[k][i] + alpha * dX[k][i];
+      for (int i = 0; i < NU; ++i) Ut[k][i] = (k < N) ? U[k][i] + alpha * dU[k][i] : 0.0;
+    }
+    for (int k = 0; k < N; ++k) {
+      double F[NXM]; step_any(c, Tk[k], Xt[k], Ut[k], F);
+      for (int i = 0; i < nx; ++i) dfc_t[k][i] = F[i] - Xt[k + 1][i];
+    }
+    for (int k = 0; k <= N; ++k) {
+      auto el = [&](const Ineq& it) { return it.el ? (it.p + alpha * it.dp) - (it.n + alpha * it.dn) : 0.0; };
+      for (int i = 0; i < NU; ++i) rR_t[k][i] = (k >= 1 && k < N && rR[k][i].on) ? (Ut[k][i] - Ut[k - 1][i]) - (rR[k][i].s + alpha * rR[k][i].ds) - el(rR[k][i]) : 0.0;
+      for (int j = 0; j < nobs; ++j) rO_t[k][j] = (k >= 1 && obs_node[k] && rO[k][j].on) ? rowval(k, j, Xt[k]) - (rO[k][j].s + alpha * rO[k][j].ds) - el(rO[k][j]) : 0.0;
+    }
+  }
+
+  // acceptance of a trial point against the filter and the current iterate (Waechter-Biegler A-5.3 / A-5.4); `alpha` is the step
+  // size that enters the switching condition and the Armijo test
+  bool trial_acceptable(const Trial& t, double alpha, double dphi, double th0, double phi0, bool& armijo_type) {
+    armijo_type = false;
+    if (!(t.ok && t.theta <= theta_max && filter_ok(t.theta, t.phi))) return false;
+    bool sw = dphi < 0 && alpha * std::pow(-dphi, o.s_phi) > o.delta * std::pow(th0, o.s_theta);
+    if (th0 <= theta_min && sw) {
+      // IPOPT's Compare_le(lhs, rhs, base): lhs - rhs <= 10 eps |base| (IpUtils.cpp), used by ArmijoHolds and
+      // IsAcceptableToCurrentIterate of IpFilterLSAcceptor.cpp: round-off slack on both acceptance tests
+      if ((t.phi - phi0) - o.eta_phi * alpha * dphi <= 10 * 2.220446049250313e-16 * std::fabs(phi0)) { armijo_type = true; return true; }
+      return false;
+    }
+    return t.theta - (1 - o.gamma_theta) * th0 <= 10 * 2.220446049250313e-16 * std::fabs(th0) ||
+           (t.phi - phi0) + o.gamma_phi * th0 <= 10 * 2.220446049250313e-16 * std::fabs(phi0);
+  }
+
+  // Second-order correction (Waechter-Biegler A-5.5 .. A-5.9; IPOPT IpFilterLSAcceptor::TrySecondOrderCorrection): when the FIRST trial
+  // point of an iteration is rejected and does not reduce the violation, the step is corrected with the constraint values at the trial
+  // point,  c_soc = alpha c_soc + c(trial)  in place of c(w_k), same matrix; up to max_soc = 4 corrections while theta shrinks by
+  // kappa_soc = 0.99.  NOT part of the shipped algorithm: the HIP kernels have no such step; the oracle
+  // carries it behind MPCO_SOC=1 to measure what it would change.  Returns the accepted step size (direction arrays then hold the
+  // corrected step, a_du its dual step size), or 0 with the original direction restored.
+  int n_soc_try = 0, n_soc_ok = 0;
+  double try_soc(const Trial& first, double a_max, double mu_, double dphi, double th0, double phi0, bool& armijo_type, double& a_du) {
+    ++n_soc_try;
+    static thread_local double dX0[NODES][NXM], dU0[NODES][NU], lamF0[NODES][NXM], dfc0[NODES][NXM], dfc_s[NODES][NXM], dfc_t[NODES][NXM];
+    static thread_local double rR_s[NODES][NU], rO_s[NODES][NOBM], rR_t[NODES][NU], rO_t[NODES][NOBM];
+    static thread_local Ineq bU0[NODES][NU], bX0[NODES][NXM], rR0[NODES][NU], rO0[NODES][NOBM];
+    std::memcpy(dX0, dX, sizeof(dX0)); std::memcpy(dU0, dU, sizeof(dU0)); std::memcpy(lamF0, lamF, sizeof(lamF0)); std::memcpy(dfc0, dfc, sizeof(dfc0));
+    for (int k = 0; k <= N; ++k) {
+      for (int i = 0; i < NU; ++i) { bU0[k][i] = bU[k][i]; rR0[k][i] = rR[k][i]; rR_s[k][i] = rR[k][i].r; }
+      for (int i = 0; i < nx; ++i) bX0[k][i] = bX[k][i];
+      for (int j = 0; j < nobs; ++j) { rO0[k][j] = rO[k][j]; rO_s[k][j] = rO[k][j].r; }
+    }
+    std::memcpy(dfc_s, dfc, sizeof(dfc_s));
+    double alpha_soc = a_max, theta_trial = first.theta, theta_old = 0;
+    for (int count = 0; count < 4 && (count == 0 || theta_trial <= 0.99 * theta_old); ++count) {
+      theta_old = theta_trial;
+      trial_residuals(alpha_soc, dfc_t, rR_t, rO_t);            // at w + alpha_soc * (direction as it stands)
+      for (int k = 0; k <= N; ++k) {
+        for (int i = 0; i < nx; ++i) dfc_s[k][i] = alpha_soc * dfc_s[k][i] + dfc_t[k][i];
+        for (int i = 0; i < NU; ++i) rR_s[k][i] = alpha_soc * rR_s[k][i] + rR_t[k][i];
+        for (int j = 0; j < nobs; ++j) rO_s[k][j] = alpha_soc * rO_s[k][j] + rO_t[k][j];
+      }
+      // the corrected step: same matrix, constraint values replaced
+      for (int k = 0; k <= N; ++k) {
+        for (int i = 0; i < nx; ++i) dfc[k][i] = dfc_s[k][i];
+        for (int i = 0; i < NU; ++i) if (rR[k][i].on) rR[k][i].r = rR_s[k][i];
+        for (int j = 0; j < nobs; ++j) if (rO[k][j].on) rO[k][j].r = rO_s[k][j];
+      }
+      solve_direction();
+      for (int k = 0; k <= N; ++k) {                             // the iterate's own residuals back (kkt_error, the next trial_residuals)
+        for (int i = 0; i < nx; ++i) dfc[k][i] = dfc0[k][i];
+        for (int i = 0; i < NU; ++i) if (rR[k][i].on) rR[k][i].r = rR0[k][i].r;
+        for (int j = 0; j < nobs; ++j) if (rO[k][j].on) rO[k][j].r = rO0[k][j].r;
+      }
+      double a_soc, a_du_soc; step_lengths(tau, a_soc, a_du_soc);
+      Trial t = eval_trial(a_soc, mu_); ++n_trial;
+      if (trial_acceptable(t, a_max, dphi, th0, phi0, armijo_type)) { ++n_soc_ok; a_du = a_du_soc; return a_soc; }
+      alpha_soc = a_soc; theta_trial = t.theta;
+    }
+    std::memcpy(dX, dX0, sizeof(dX0)); std::memcpy(dU, dU0, sizeof(dU0)); std::memcpy(lamF, lamF0, sizeof(lamF0));
+    for (int k = 0; k <= N; ++k) {
+      for (int i = 0; i < NU; ++i) { bU[k][i] = bU0[k][i]; rR[k][i] = rR0[k][i]; }
+      for (int i = 0; i < nx; ++i) bX[k][i] = bX0[k][i];
+      for (int j = 0; j < nobs; ++j) rO[k][j] = rO0[k][j];
+    }
+    armijo_type = false;
+    return 0.0;
+  }
+  static bool soc_enabled() { static const bool on = [] { const char* e = std::getenv("MPCO_SOC"); return e && e[0] == '1'; }(); return on; }
+
+  // IPOPT's filter line search (Waechter-Biegler Alg. A, steps A-5); the second-order correction only with MPCO_SOC=1 (see try_soc).
+  // Returns the accepted alpha, or 0 when alpha fell under alpha_min.  a_du: replaced when a corrected step is accepted.
+  double line_search(double a_max, double mu_, double dphi, bool& armijo_type, double& a_du) {
     const double phi0 = barrier_phi(fval, mu_), th0 = theta;
     double a_min;
     if (dphi < 0) {
@@ -897,19 +988,19 @@ struct Solver {
     while (true) {
       Trial t = eval_trial(alpha, mu_);
       ++n_trial;
-      if (t.ok && t.theta <= theta_max && filter_ok(t.theta, t.phi)) {
-        bool sw = dphi < 0 && alpha * std::pow(-dphi, o.s_phi) > o.delta * std::pow(th0, o.s_theta);
-        if (th0 <= theta_min && sw) {
-          // IPOPT's Compare_le(lhs, rhs, base): lhs - rhs <= 10 eps |base| (IpUtils.cpp), used by ArmijoHolds and
-          // IsAcceptableToCurrentIterate of IpFilterLSAcceptor.cpp: round-off slack on both acceptance tests
-          if ((t.phi - phi0) - o.eta_phi * alpha * dphi <= 10 * 2.220446049250313e-16 * std::fabs(phi0)) { armijo_type = true; return alpha; }
-        } else if (t.theta - (1 - o.gamma_theta) * th0 <= 10 * 2.220446049250313e-16 * std::fabs(th0) ||
-                   (t.phi - phi0) + o.gamma_phi * th0 <= 10 * 2.220446049250313e-16 * std::fabs(phi0)) return alpha;
+      if (trial_acceptable(t, alpha, dphi, th0, phi0, armijo_type)) return alpha;
+      if (alpha == a_max) {
+        ++n_first_rejected; if (t.theta >= th0) ++n_first_rejected_theta_up;
+        if (soc_enabled() && t.ok && t.theta >= th0) {
+          const double a = try_soc(t, a_max, mu_, dphi, th0, phi0, armijo_type, a_du);
+          if (a > 0) return a;
+        }
       }
       alpha *= 0.5;
       if (alpha < a_min || alpha < 1e-16) return 0.0;
     }
   }
+  int n_first_rejected = 0, n_first_rejected_theta_up = 0;
 
   void apply_step(double alpha, double alpha_du, double mu_) {
     for (int k = 0; k <= N; ++k) {
@@ -958,7 +1049,7 @@ struct Solver {
     solve_direction();
     step_lengths(tau, a_pr, a_du);
     dphi = dir_deriv(mu);
-    alpha = line_search(a_pr, mu, dphi, armijo_type);
+    alpha = line_search(a_pr, mu, dphi, armijo_type, a_du);
     if (debug) std::fprintf(stderr, "%s %3d mu %.2e E0 %.3e th %.3e f %.8e a_pr %.3e a %.3e a_du %.3e dw %.1e dphi %.2e |F|=%zu\n", resto ? "R " : "it",
                             iters, mu, err0, theta, fval, a_pr, alpha, a_du, dw_used, dphi, filter.size());
     if (debug) {   // the item that limits the primal step
@@ -1170,7 +1261,8 @@ struct Solver {
     }
     if (obj) { set_main_cost(); *obj = objective(X, U); }
     if (st) *st = status;
-    if (std::getenv("MPCO_STATS")) std::fprintf(stderr, "STATS %d %d %d %d %d %d\n", status, iters, n_factor, n_trial, n_resto_calls, n_resto_iters);
+    if (std::getenv("MPCO_STATS")) std::fprintf(stderr, "STATS %d %d %d %d %d %d %d %d %d %d\n", status, iters, n_factor, n_trial, n_resto_calls, n_resto_iters,
+                                                 n_first_rejected, n_first_rejected_theta_up, n_soc_try, n_soc_ok);
     if (it) *it = iters + iters_prev;
     if (kkt) {
       double du = 0; Err e = kkt_error(0.0, &du);

@@ -220,3 +220,23 @@ def test_second_start_follows_the_kind_of_start():
     e = oracle.solve(one, x0, xs, obs, z0=z0, want_multipliers=False)
     assert np.array_equal(c["z"], d["z"]) and np.array_equal(c["status"], d["status"]) and np.array_equal(c["iters"], d["iters"])
     assert not np.array_equal(c["iters"], e["iters"])                       # (the two orders do differ on this batch)
+
+
+def test_second_order_correction_experiment_switch():
+    """MPCO_SOC=1 (a subprocess: the switch is read once per process) turns on the oracle's second-order correction — an experiment
+    that measures what IPOPT's A-5.5..5.9 would change, not part of the shipped algorithm: it must run, keep
+    every solved instance solved on this batch and change only a few iteration counts; without the switch results are the goldens'."""
+    import subprocess, sys, json
+    code = ("import numpy as np, json, sys; sys.path.insert(0, %r); from oracle import oracle; from mpc_motion_planning_amd import scenes;"
+            "x0, xs, obs = scenes.sample_c2(256, seed=0); c = oracle.default_config(N=30, n_obs=1); c.init_rollout = 1; c.mu_init = 10.0; c.second_start = 3;"
+            "r = oracle.solve(c, x0, xs, obs, want_multipliers=False); print(json.dumps({'status': r['status'].tolist(), 'iters': r['iters'].tolist()}))"
+            % os.path.join(os.path.dirname(__file__), ".."))
+    out = {}
+    for tag, env in (("off", {}), ("on", {"MPCO_SOC": "1"})):
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env={**os.environ, **env}, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out[tag] = json.loads(p.stdout.strip().splitlines()[-1])
+    st0, st1 = np.array(out["off"]["status"]), np.array(out["on"]["status"])
+    it0, it1 = np.array(out["off"]["iters"]), np.array(out["on"]["iters"])
+    assert (st1 == 0).sum() >= (st0 == 0).sum() - 1 and (st0 != st1).sum() <= 2
+    assert 0 < (it0 != it1).sum() <= 0.1 * len(it0) and abs(int(it1.sum()) - int(it0.sum())) <= 0.02 * it0.sum()

@@ -18,10 +18,9 @@ if bench:
 # one solve = several launches (round 3: first attempt, second start, restoration pass — 1..4 by cfg.restoration / cfg.second_start):
 # every launch of the LAST solve of the run gets its own block; sums over them are "per solve launch" figures
 cfgb = bench.get("config", {})
-ss, resto = int(cfgb.get("second_start", 0) or 0), bool(cfgb.get("restoration", True))
-if ss == 3:
-    ss = 2 if "warm" in cfgb.get("workload", "").lower() else 1        # by the kind of start (include/mpcbatch.h)
-n_launch = 1 + (1 if ss else 0) + ((2 if ss == 2 else 1) if resto else 0)
+n_launch = int(cfgb.get("kernel_launches_per_solve") or 0)
+if not n_launch:                       # bench lines older than that field: three launches (first attempt, second start, restoration pass)
+    n_launch = 3
 allv = {}
 for g in "abcde":
     files = glob.glob(os.path.join(out, "pmc" + g, "**", "*counter_collection.csv"), recursive=True)
@@ -29,7 +28,10 @@ for g in "abcde":
         continue
     rows = list(csv.DictReader(open(files[0])))
     rows = [r for r in rows if "mpcb_kernel" in r["Kernel_Name"]]
-    ids = sorted(set(int(r["Dispatch_Id"]) for r in rows))[-n_launch:]
+    all_ids = sorted(set(int(r["Dispatch_Id"]) for r in rows))
+    if len(all_ids) % n_launch:
+        lines.append("# WARNING: %d solve-kernel dispatches are not a multiple of %d launches per solve" % (len(all_ids), n_launch))
+    ids = all_ids[-n_launch:]
     for pos, did in enumerate(ids):
         sel = [r for r in rows if int(r["Dispatch_Id"]) == did]
         waves = int(sel[0]["Grid_Size"]) // int(sel[0]["Workgroup_Size"])
