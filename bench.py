@@ -81,12 +81,12 @@ def parity_evidence():
 def kernel_launches_per_solve(cfg, with_z0):
     """Kernel launches behind one mpcb_solve_device call, as mpcb_api.hip's launch_solve orders them (used by tools/summarize_profile.py to
     add up the counters of one solve): first attempt, [its restoration pass], [second start — none where the kernel runs it inside the first
-    launch: kin<0>, kin<1> with a second start of kind 1], [restoration pass]."""
+    launch: the kin and dyn instantiations for up to three obstacles (no general-gamma rows, no RK4) with a second start of kind 1], [restoration pass]."""
     from mpc_motion_planning_amd import _abi
     second = bool(cfg.second_start) and bool(cfg.init_rollout)
     kind = (2 if with_z0 else 1) if cfg.second_start == 3 else int(cfg.second_start)
     gen = cfg.model == _abi.MODEL_KIN and cfg.obs_mode == _abi.OBS_DCBF and cfg.gamma < 1.0 - 1e-12 and cfg.n_obs > 0
-    fused = second and kind == 1 and cfg.model == _abi.MODEL_KIN and cfg.n_obs <= 1 and not gen and cfg.integrator != _abi.INT_RK4
+    fused = second and kind == 1 and cfg.n_obs <= 3 and (cfg.model == _abi.MODEL_DYN or (not gen and cfg.integrator != _abi.INT_RK4))
     n = 1
     if cfg.restoration and not (second and kind == 1):
         n += 1
@@ -314,7 +314,7 @@ def main():
                          "obstacles B=32768; C4 dyn N=40 3 obstacles B=8192/GPU; C5 closed loop 80 steps (solves = scenes x steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-restoration", action="store_true", help="cfg.restoration = 0: a failed line search ends the solve (round-1 behaviour)")
-    ap.add_argument("--inflight", type=int, default=6,
+    ap.add_argument("--inflight", type=int, default=8,
                     help="launch lanes of the solver handle (mpcb_set_inflight): a batch is cut into that many chunks, chunk c of step k+1 "
                          "starts when chunk c of step k has finished, while the slowest instances of the other chunks still run (a launch "
                          "ends with its slowest instance and leaves most SIMDs idle before that); 1 = strictly one launch at a time")

@@ -24,7 +24,7 @@
  *   - one handle = one device + one stream (+ optional launch lanes, mpcb_set_inflight); calls on one handle must be
  *     serialised by the caller (one host thread at a time).  A launch ends with its slowest instance, so throughput needs
  *     several launches in flight: mpcb_set_inflight(h, k) lets consecutive asynchronous mpcb_solve_device calls of ONE handle
- *     overlap (bench.py's default: one handle, six lanes); distinct handles are independent as well.
+ *     overlap (bench.py's default: one handle, eight lanes); distinct handles are independent as well.
  *   - buffers of solves that are in flight at the same time (lanes, or several handles) must be distinct: in particular the
  *     status array, through which the two passes of a solve communicate.
  */

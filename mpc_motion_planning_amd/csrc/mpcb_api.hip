@@ -36,8 +36,10 @@ thread_local std::string g_create_error;
 // pass of its own (launch_solve).  -DMPCB_NO_FUSED_SECOND: no instantiation fuses (A/B builds).
 #ifdef MPCB_NO_FUSED_SECOND
 template <int NOBS, bool GEN, bool RK4> constexpr bool mpcb_kin_fuses = false;
+template <int NOBS> constexpr bool mpcb_dyn_fuses = false;
 #else
-template <int NOBS, bool GEN, bool RK4> constexpr bool mpcb_kin_fuses = NOBS <= 1 && !GEN && !RK4;
+template <int NOBS, bool GEN, bool RK4> constexpr bool mpcb_kin_fuses = NOBS <= 3 && !GEN && !RK4;
+template <int NOBS> constexpr bool mpcb_dyn_fuses = NOBS <= 3;
 #endif
 __host__ __device__ inline bool mpcb_second_kind1(const mpcb_config& c, const void* z0) {   // cfg.second_start = 3: by the kind of start
   return c.init_rollout && (c.second_start == 1 || (c.second_start == 3 && !z0));
@@ -75,7 +77,17 @@ __global__ __launch_bounds__(64, 1) void mpcb_kernel_kin_resto(const MpcbKArgs a
 template <int NOBS>
 __global__ __launch_bounds__(64, MPCB_WAVES_PER_SIMD) void mpcb_kernel_dyn(const MpcbKArgs a) {
   extern __shared__ __attribute__((aligned(16))) double mpcb_lds[];
-  mpcb_solve_dyn<NOBS>(a, (int)blockIdx.x, mpcb_lds, a.pass);
+  if constexpr (mpcb_dyn_fuses<NOBS>) {
+    int pass = a.pass;
+#pragma clang loop unroll(disable)
+    for (;;) {
+      mpcb_solve_dyn<NOBS>(a, (int)blockIdx.x, mpcb_lds, pass);
+      if (!mpcb_second_attempt_here(a, (int)blockIdx.x, pass)) break;
+      pass = MPCB_PASS_SECOND;
+    }
+  } else {
+    mpcb_solve_dyn<NOBS>(a, (int)blockIdx.x, mpcb_lds, a.pass);
+  }
 }
 
 template <int NOBS>
@@ -598,8 +610,10 @@ int launch_solve(mpcb_handle* h, const MpcbKArgs& a_in, int lane_id = 0) {
   if (rc == MPCB_OK && h->cfg.restoration && !(second_pass(h->cfg) && ss == 1)) rc = resto_pass();
   if (rc == MPCB_OK && second_pass(h->cfg)) {
     // (kind 1 on an instantiation that fuses: the second attempt ran inside the first launch)
-    const bool fused = ss == 1 && h->cfg.model == MPCB_MODEL_KIN && !is_gen(h->cfg) && !is_rk4(h->cfg) &&
-                       ((n == 0 && mpcb_kin_fuses<0, false, false>) || (n == 1 && mpcb_kin_fuses<1, false, false>));
+    const bool fused = ss == 1 && (h->cfg.model == MPCB_MODEL_DYN
+                                       ? ((n <= 1 && mpcb_dyn_fuses<1>) || (n > 1 && n <= 3 && mpcb_dyn_fuses<3>))
+                                       : (!is_gen(h->cfg) && !is_rk4(h->cfg) && ((n == 0 && mpcb_kin_fuses<0, false, false>) || (n == 1 && mpcb_kin_fuses<1, false, false>) ||
+                                                                                   (n > 1 && n <= 3 && mpcb_kin_fuses<3, false, false>))));
     if (!fused) rc = lean_pass(MPCB_PASS_SECOND);
     if (rc == MPCB_OK && h->cfg.restoration) rc = resto_pass();
   }

@@ -145,7 +145,7 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a_in, const int b, double* lds, 
   // the eight vehicle / tyre constants of the model are loaded from the kernel arguments at every model evaluation instead of living in
   // 16+ scalar registers for the whole solve (wv::late_args): the dyn kernels spill SGPRs into VGPR lanes by the hundred
   auto MC = [&]() -> const mpcb_config& { return wv::late_args(a)->cfg; };
-  const int N = c.N, lane = wv::lane(), k = lane;
+  const int N = c.N, lane = wv::opaque(wv::lane()), k = lane;     // (opaque: see mpcb_kernel.h)
   const int nz = a.nz, nobs = c.n_obs;
   if (RESTO && a.status[(size_t)b * a.st_stride] != MPCB_ST_NEEDS_RESTO) return;     // wave-uniform: this instance is done
   if (!RESTO && pass == MPCB_PASS_SECOND) {          // second start: only instances whose first attempt (restoration included) did not succeed
