@@ -322,6 +322,9 @@ def main():
     ap.add_argument("--batches", type=int, default=5,
                     help="distinct synthetic batches resident in HBM, used round-robin by the steps (the launch time of a 4096-instance "
                          "batch moves +-15 %% with where its slowest instances fall in the dispatch order; one batch would report one draw)")
+    ap.add_argument("--start-steer", type=float, default=None,
+                    help="cfg.start_steer [rad] (default: what mpcb_default_config ships, 0.03): the slight constant turn of a cold start whose straight "
+                         "roll-out runs into an obstacle row; 0 = the straight roll-out of rounds 1-2")
     ap.add_argument("--second-start", type=int, default=None, choices=[0, 1, 2, 3],
                     help="cfg.second_start (default: what mpcb_default_config ships, 3 = by the kind of start: 1 for a cold start, 2 with a start "
                          "vector): 0 = one attempt per instance (round-2 behaviour), 1 = second attempt instead of the first attempt's restoration "
@@ -376,6 +379,8 @@ def main():
         cfg.restoration = 0
     if args.second_start is not None:
         cfg.second_start = args.second_start
+    if args.start_steer is not None:
+        cfg.start_steer = args.start_steer
     if args.integrator == "rk4":
         cfg.integrator = _abi.INT_RK4
         workload += " [RK4 shooting rows]"
@@ -507,7 +512,7 @@ def main():
         it_ok = iters[status == 0]
         flop_iter = 147e3 if cfg.model == _abi.MODEL_DYN else 56e3                  # ~56 kflop (kin N=30) / ~147 kflop (dyn N=40) per iteration
         flops_model = flop_iter * iters_per_launch / B * inst_per_launch            # model flops of one launch
-        ctr = measured_counters(workload, {"second_start": int(cfg.second_start), "restoration": bool(cfg.restoration),
+        ctr = measured_counters(workload, {"second_start": int(cfg.second_start), "restoration": bool(cfg.restoration), "start_steer": float(cfg.start_steer),
                                            "integrator": "rk4" if cfg.integrator == _abi.INT_RK4 else "euler"})
         flops_ctr = (ctr["fp64_flop_per_launch"] / B * inst_per_launch) if ctr.get("fp64_flop_per_launch") else None
         traffic = (ctr["bytes_per_launch"] / B * inst_per_launch) if ctr.get("bytes_per_launch") else None
@@ -524,7 +529,8 @@ def main():
                        "status_histogram_rank0": {str(k): int(v) for k, v in enumerate(np.bincount(status, minlength=7))},
                        "iters_mean_solved": float(it_ok.mean()) if len(it_ok) else None, "iters_max": int(iters.max()),
                        "iters_share_of_unsolved": float(iters[status != 0].sum() / max(1, iters.sum())),
-                       "restoration": bool(cfg.restoration), "second_start": int(cfg.second_start), "integrator": "rk4" if cfg.integrator == _abi.INT_RK4 else "euler",
+                       "restoration": bool(cfg.restoration), "second_start": int(cfg.second_start), "start_steer": float(cfg.start_steer),
+                       "integrator": "rk4" if cfg.integrator == _abi.INT_RK4 else "euler",
                        "kernel_launches_per_solve": kernel_launches_per_solve(cfg, d_z0 is not None),
                        "solver_handles": HN, "launch_lanes_per_handle": F, "launches_per_step": launches / args.steps, "tol": cfg.tol,
                        "collective": "RCCL all-gather of z per step inside libmpcbatch (mpcb_allgather), overlapped with the next steps' solves" if grp.active else "none",

@@ -153,6 +153,13 @@ typedef struct mpcb_config {
                                               0: one attempt, as IPOPT.
                                             `iters` counts both attempts, each has max_iter of its own.  Without a roll-out (init_rollout = 0:
                                             the start taken as given, IPOPT's behaviour) there is one attempt, whatever this field says. */
+  double   start_steer;                  /* Cold start only (z0 = NULL, init_rollout = 1, n_obs > 0).  The roll-out from zero controls is a straight
+                                            line; when it passes an obstacle row closer than h - obs_hmin < 1 at some node, it is replaced by the
+                                            roll-out with the constant steering angle +-start_steer [rad] (acceleration 0): away from the centre of
+                                            that obstacle, or to its other side when the y box (x_lo[1], x_hi[1]) leaves no room for the row's
+                                            ellipse on that side.  A straight path that runs head-on into an obstacle is a stationary point of the
+                                            violation at which an interior-point iteration stalls; the slight turn breaks the tie.
+                                            mpcb_default_config: 0.03; 0 = off (the start of rounds 1-2). */
 } mpcb_config;
 
 typedef struct mpcb_handle mpcb_handle;

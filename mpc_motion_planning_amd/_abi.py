@@ -47,7 +47,7 @@ class MpcbConfig(C.Structure):
         ("dual_inf_tol", _d), ("constr_viol_tol", _d), ("compl_inf_tol", _d),
         ("acceptable_tol", _d), ("acceptable_obj_change_tol", _d), ("acceptable_constr_viol_tol", _d),
         ("acceptable_dual_inf_tol", _d), ("acceptable_compl_inf_tol", _d),
-        ("acceptable_iter", _i), ("second_start", _i),
+        ("acceptable_iter", _i), ("second_start", _i), ("start_steer", _d),
     ]
 
     def copy(self):

@@ -414,6 +414,7 @@ int check_cfg(mpcb_handle* h, const mpcb_config* c) {
     return fail(h, MPCB_E_UNSUPPORTED, "MPCB_INT_RK4 is built for the kinematic model with up to 3 obstacles and keep-out / gamma = 1 rows");
   if (c->restoration != 0 && c->restoration != 1) return fail(h, MPCB_E_INVALID, "restoration must be 0 or 1");
   if (c->second_start < 0 || c->second_start > 3) return fail(h, MPCB_E_INVALID, "second_start must be 0, 1, 2 or 3");
+  if (!(c->start_steer >= 0.0 && c->start_steer <= 0.5)) return fail(h, MPCB_E_INVALID, "start_steer must be in [0, 0.5] rad");
   if (std::isfinite(c->x_lo[0]) || std::isfinite(c->x_hi[0]) || std::isfinite(c->x_lo[2]) || std::isfinite(c->x_hi[2]))
     return fail(h, MPCB_E_UNSUPPORTED, "state boxes are supported on y, vx (and vy for the dynamic model) (kin.py:97-105, dyn.py:97-110)");
   if (c->model == MPCB_MODEL_KIN) {
@@ -714,6 +715,7 @@ int mpcb_default_config(mpcb_config* cfg, int32_t model, int32_t N, double T) {
   c.acceptable_tol = 1e-8; c.acceptable_obj_change_tol = 1e-6; c.acceptable_iter = 15;
   c.acceptable_constr_viol_tol = 1e-2; c.acceptable_dual_inf_tol = 1e10; c.acceptable_compl_inf_tol = 1e-2;
   c.second_start = 3;
+  c.start_steer = 0.03;
   *cfg = c;
   return MPCB_OK;
 }

@@ -525,18 +525,43 @@ MPCB_DEVFN void mpcb_solve_kin(const MpcbKArgs& a_in, const int b, double* lds, 
 
   // optional roll-out of X from x0 with the guessed (clipped) controls
   if (!RESTO && rollout) {
-    U[0] = hasu ? fmin(fmax(U[0], c.u_lo[0]), c.u_hi[0]) : 0.0;
-    U[1] = hasu ? fmin(fmax(U[1], c.u_lo[1]), c.u_hi[1]) : 0.0;
-    double sd, cd; sincos_b(U[0], sd, cd);
-    const double tdr = sd * wv::rcp(cd);
+    auto roll_out = [&]() {
+      U[0] = hasu ? fmin(fmax(U[0], c.u_lo[0]), c.u_hi[0]) : 0.0;
+      U[1] = hasu ? fmin(fmax(U[1], c.u_lo[1]), c.u_hi[1]) : 0.0;
+      double sd, cd; sincos_b(U[0], sd, cd);
+      const double tdr = sd * wv::rcp(cd);
 #pragma clang loop unroll(disable)
-    for (int s = 0; s < N; ++s) {
-      double sps, cps; sincos_b(X[2], sps, cps);
-      const double v = X[3];
-      double F0 = X[0] + T * (v * cps), F1 = X[1] + T * (v * sps), F2 = X[2] + T * (v * tdr * il), F3 = X[3] + T * U[1];
-      if (RK4) { double Fr[NX]; kin_rk4_step(X, U, T, il, sps, cps, tdr, Fr); F0 = Fr[0]; F1 = Fr[1]; F2 = Fr[2]; F3 = Fr[3]; }
-      const double n0 = wv::bcast(F0, s), n1 = wv::bcast(F1, s), n2 = wv::bcast(F2, s), n3 = wv::bcast(F3, s);
-      if (k == s + 1) { X[0] = n0; X[1] = n1; X[2] = n2; X[3] = n3; }
+      for (int s = 0; s < N; ++s) {
+        double sps, cps; sincos_b(X[2], sps, cps);
+        const double v = X[3];
+        double F0 = X[0] + T * (v * cps), F1 = X[1] + T * (v * sps), F2 = X[2] + T * (v * tdr * il), F3 = X[3] + T * U[1];
+        if (RK4) { double Fr[NX]; kin_rk4_step(X, U, T, il, sps, cps, tdr, Fr); F0 = Fr[0]; F1 = Fr[1]; F2 = Fr[2]; F3 = Fr[3]; }
+        const double n0 = wv::bcast(F0, s), n1 = wv::bcast(F1, s), n2 = wv::bcast(F2, s), n3 = wv::bcast(F3, s);
+        if (k == s + 1) { X[0] = n0; X[1] = n1; X[2] = n2; X[3] = n3; }
+      }
+    };
+    roll_out();
+    // cfg.start_steer (include/mpcbatch.h; oracle: Solver::init): a cold start whose straight roll-out passes an obstacle row closer than
+    // h - obs_hmin < 1 is rolled out with a slight constant turn instead — away from the centre of that obstacle (the first minimum of
+    // h over the nodes, then over the obstacles of a node), or to its other side when the y box has no room for the row's ellipse there
+    if (NOBS > 0 && !a.z0 && nobs > 0 && wv::late_args(a)->cfg.start_steer > 0.0) {       // wave-uniform
+      double hm = 1e300, oyk = 0.0, iyk = 1.0;
+#pragma unroll
+      for (int j = 0; j < NOBS; ++j) if (j < nobs) {
+        const double hj = hval(j, X[0], X[1]) - c.obs_hmin;
+        if (hj < hm) { hm = hj; oyk = oy(j); iyk = iy2(j); }
+      }
+      if (!(obs_node && k >= 1)) hm = 1e300;
+      const double hw = wv::uni(wv::min(hm));
+      if (hw < 1.0) {
+        const int kb = (int)wv::uni(wv::min(hm == hw ? (double)k : 1e9));      // the first node at which the minimum is taken
+        const double py = wv::shfl(X[1], kb), qy = wv::shfl(oyk, kb), sy = 1.0 / sqrt(wv::shfl(iyk, kb));
+        double sgn = py >= qy ? 1.0 : -1.0;
+        const bool up = qy + sy <= c.x_hi[1], dn = qy - sy >= c.x_lo[1];
+        if (sgn > 0 && !up && dn) sgn = -1.0; else if (sgn < 0 && !dn && up) sgn = 1.0;
+        U[0] = hasu ? sgn * wv::late_args(a)->cfg.start_steer : 0.0;
+        roll_out();
+      }
     }
   }
 

@@ -342,18 +342,42 @@ MPCB_DEVFN void mpcb_solve_dyn(const MpcbKArgs& a_in, const int b, double* lds, 
   const bool ducost = hasu && (k > 0 || c.du0_cost);     // (U_k - U_{k-1})' DR (.) present in stage k     dyn.py:221-224
 
   if (!RESTO && rollout) {
-    U[0] = hasu ? fmin(fmax(U[0], c.u_lo[0]), c.u_hi[0]) : 0.0;
-    U[1] = hasu ? fmin(fmax(U[1], c.u_lo[1]), c.u_hi[1]) : 0.0;
+    auto roll_out = [&]() {
+      U[0] = hasu ? fmin(fmax(U[0], c.u_lo[0]), c.u_hi[0]) : 0.0;
+      U[1] = hasu ? fmin(fmax(U[1], c.u_lo[1]), c.u_hi[1]) : 0.0;
 #pragma clang loop unroll(disable)
-    for (int s = 0; s < N; ++s) {
-      double Xs[NX]; bool okx = X[3] > 1e-3;
+      for (int s = 0; s < N; ++s) {
+        double Xs[NX]; bool okx = X[3] > 1e-3;
 #pragma unroll
-      for (int i = 0; i < NX; ++i) Xs[i] = X[i];
-      if (!okx) Xs[3] = 1e-3;
-      DynEval e; dyn_eval(MC(), Xs, U, e);
-      double F[NX]; dyn_F(MC(), T, Xs, U, e, F);
+        for (int i = 0; i < NX; ++i) Xs[i] = X[i];
+        if (!okx) Xs[3] = 1e-3;
+        DynEval e; dyn_eval(MC(), Xs, U, e);
+        double F[NX]; dyn_F(MC(), T, Xs, U, e, F);
 #pragma unroll
-      for (int i = 0; i < NX; ++i) { const double n = wv::bcast(F[i], s); if (k == s + 1) X[i] = n; }
+        for (int i = 0; i < NX; ++i) { const double n = wv::bcast(F[i], s); if (k == s + 1) X[i] = n; }
+      }
+    };
+    roll_out();
+    // cfg.start_steer: a cold start whose straight roll-out passes an obstacle row closer than h - obs_hmin < 1 is rolled out with a
+    // slight constant turn instead (see mpcb_kernel.h; oracle: Solver::init)
+    if (NOBS > 0 && !a.z0 && nobs > 0 && MC().start_steer > 0.0) {       // wave-uniform
+      double hm = 1e300, oyk = 0.0, iyk = 1.0;
+#pragma unroll
+      for (int j = 0; j < NOBS; ++j) if (j < nobs) {
+        const double hj = hval(j, X[0], X[1]) - c.obs_hmin;
+        if (hj < hm) { hm = hj; oyk = oy(j); iyk = iy2(j); }
+      }
+      if (!(obs_node && k >= 1)) hm = 1e300;
+      const double hw = wv::uni(wv::min(hm));
+      if (hw < 1.0) {
+        const int kb = (int)wv::uni(wv::min(hm == hw ? (double)k : 1e9));      // the first node at which the minimum is taken
+        const double py = wv::shfl(X[1], kb), qy = wv::shfl(oyk, kb), sy = 1.0 / sqrt(wv::shfl(iyk, kb));
+        double sgn = py >= qy ? 1.0 : -1.0;
+        const bool up = qy + sy <= c.x_hi[1], dn = qy - sy >= c.x_lo[1];
+        if (sgn > 0 && !up && dn) sgn = -1.0; else if (sgn < 0 && !dn && up) sgn = 1.0;
+        U[0] = hasu ? sgn * MC().start_steer : 0.0;
+        roll_out();
+      }
     }
   }
 

@@ -448,10 +448,34 @@ struct Solver {
     }
 
     // optional roll-out of X from x0 with the guessed (clipped) controls
-    if (rollout) {
+    auto roll_out = [&]() {
       for (int k = 0; k < N; ++k) {
         double Uc[NU]; for (int i = 0; i < NU; ++i) Uc[i] = std::min(std::max(U[k][i], c.u_lo[i]), c.u_hi[i]);
         step_any(c, Tk[k], X[k], Uc, X[k + 1]);
+      }
+    };
+    if (rollout) {
+      roll_out();
+      // cfg.start_steer (include/mpcbatch.h; the kernels' set-up does the same): a cold start whose straight roll-out passes an obstacle
+      // row closer than h - obs_hmin < 1 is rolled out with a slight constant turn instead — away from the centre of that obstacle
+      // (the first minimum of h over the nodes, then over the obstacles of a node), or to its other side when the y box has no room
+      // for the row's ellipse on that side
+      if (!z0 && c.start_steer > 0.0 && nobs > 0) {
+        double hm = 1e300; int kb = -1, jb = -1;
+        for (int k = 1; k <= N; ++k) if (obs_node[k]) {
+          double hk = 1e300; int jk = 0;
+          for (int j = 0; j < nobs; ++j) { const double hj = hval(k, j, X[k]) - c.obs_hmin; if (hj < hk) { hk = hj; jk = j; } }
+          if (hk < hm) { hm = hk; kb = k; jb = jk; }
+        }
+        if (kb >= 0 && hm < 1.0) {
+          const ObsP& q = obs[kb][jb];
+          const double sy = 1.0 / std::sqrt(q.iy2);
+          double sgn = X[kb][1] >= q.oy ? 1.0 : -1.0;
+          const bool up = q.oy + sy <= c.x_hi[1], dn = q.oy - sy >= c.x_lo[1];
+          if (sgn > 0 && !up && dn) sgn = -1.0; else if (sgn < 0 && !dn && up) sgn = 1.0;
+          for (int k = 0; k < N; ++k) U[k][0] = sgn * c.start_steer;
+          roll_out();
+        }
       }
     }
 
@@ -1365,6 +1389,7 @@ int mpco_default_config(mpcb_config* cfg, int32_t model, int32_t N, double T) {
   c.acceptable_tol = 1e-8; c.acceptable_obj_change_tol = 1e-6; c.acceptable_iter = 15;         // kin.py:252-253, IPOPT acceptable_iter
   c.acceptable_constr_viol_tol = 1e-2; c.acceptable_dual_inf_tol = 1e10; c.acceptable_compl_inf_tol = 1e-2;
   c.second_start = 0;                          // (the oracle's own defaults are IPOPT's: one attempt from the given start)
+  c.start_steer = 0.0;
   return MPCB_OK;
 }
 

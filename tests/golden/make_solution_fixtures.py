@@ -21,7 +21,7 @@ out = {}
 
 def product_cfg(N, n_obs):
     c = oracle.default_config(N=N, n_obs=n_obs)
-    c.init_rollout = 1; c.mu_init = 10.0; c.second_start = 3   # the settings mpcb_default_config ships
+    c.init_rollout = 1; c.mu_init = 10.0; c.second_start = 3; c.start_steer = 0.03   # the settings mpcb_default_config ships
     return c
 
 
@@ -70,14 +70,14 @@ out.update(W_x0=x1, W_z0=z0, W_z=rw["z"], W_obj=rw["obj"], W_iters=rw["iters"])
 print("W:", rw["obj"], rw["iters"])
 
 # D: dynamic bicycle, shipped closed-loop scene, first step (main_cbf_dyn_c_sim.py:44-51) at N = 40 (BASELINE C4 horizon)
-cd = oracle.default_config(model=_abi.MODEL_DYN, N=40, n_obs=1); cd.init_rollout = 1; cd.mu_init = 10.0; cd.second_start = 3
+cd = oracle.default_config(model=_abi.MODEL_DYN, N=40, n_obs=1); cd.init_rollout = 1; cd.mu_init = 10.0; cd.second_start = 3; cd.start_steer = 0.03
 rd = oracle.solve(cd, scenes.DYN_X0[None], scenes.DYN_XS[None], scenes.DYN_OBS[None])
 assert rd["status"][0] == 0
 out.update(D_z=rd["z"], D_obj=rd["obj"], D_lam_g=rd["lam_g"], D_lam_x=rd["lam_x"], D_iters=rd["iters"])
 print("D:", rd["obj"], rd["iters"])
 # C4: 8 seeded dyn scenes with 3 static obstacles
 x0, xs, obs = scenes.sample_c4(8, seed=13, n_obs=3)
-c4 = oracle.default_config(model=_abi.MODEL_DYN, N=40, n_obs=3); c4.init_rollout = 1; c4.mu_init = 10.0; c4.second_start = 3
+c4 = oracle.default_config(model=_abi.MODEL_DYN, N=40, n_obs=3); c4.init_rollout = 1; c4.mu_init = 10.0; c4.second_start = 3; c4.start_steer = 0.03
 r4 = oracle.solve(c4, x0, xs, obs)
 out.update(C4_x0=x0, C4_xs=xs, C4_obs=obs, C4_z=r4["z"], C4_obj=r4["obj"], C4_status=r4["status"], C4_iters=r4["iters"])
 print("C4:", r4["status"], r4["iters"])

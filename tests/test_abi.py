@@ -111,4 +111,4 @@ def test_integration_stub_declares_the_same_struct():
     cfg = stub()
     raw = C.CDLL(_lib.lib()._name)                       # an untyped binding, as the stub's own C.CDLL(...)
     assert raw.mpcb_default_config(C.byref(cfg), 0, C.c_int32(30), C.c_double(0.1)) == 0 and cfg.struct_size == C.sizeof(stub)
-    assert cfg.second_start == 3 and cfg.acceptable_iter == 15 and cfg.acceptable_tol == 1e-8
+    assert cfg.second_start == 3 and cfg.acceptable_iter == 15 and cfg.acceptable_tol == 1e-8 and cfg.start_steer == 0.03

@@ -72,7 +72,8 @@ if bench and (tot_f or tot_w):
     wc = first.get("SQ_WAVE_CYCLES", 0.0)
     json.dump({"workload_key": wl.split(":")[0], "workload": wl, "round": sys.argv[2] if len(sys.argv) > 2 else None, "fetch_kib": tot_f, "write_kib": tot_w,
                "bytes_per_launch": (2 * tot_f + tot_w) * 1024.0, "fp64_flop_per_launch": fp64 or None, "launches_per_solve": n_launch,
-               "settings": {"second_start": cfgb.get("second_start"), "restoration": cfgb.get("restoration"), "integrator": cfgb.get("integrator")},
+               "settings": {"second_start": cfgb.get("second_start"), "restoration": cfgb.get("restoration"), "integrator": cfgb.get("integrator"),
+                            "start_steer": cfgb.get("start_steer")},
                "valu_busy": (first.get("SQ_ACTIVE_INST_VALU", 0.0) / wc) if wc else None, "wait_any": (first.get("SQ_WAIT_ANY", 0.0) / wc) if wc else None},
               open(os.path.join(out, "traffic.json"), "w"))
 open(os.path.join(out, "pmc.txt"), "w").write("\n".join(lines) + "\n")
