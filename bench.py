@@ -35,7 +35,7 @@ if ROOT not in sys.path:
 
 # HIP maps streams onto a small pool of hardware queues (default 4 per process) and two streams on one queue run one
 # after the other; RCCL takes some too.  More queues keep the solver handles' streams (--inflight) concurrent.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (spec)
@@ -314,7 +314,7 @@ def main():
                          "obstacles B=32768; C4 dyn N=40 3 obstacles B=8192/GPU; C5 closed loop 80 steps (solves = scenes x steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-restoration", action="store_true", help="cfg.restoration = 0: a failed line search ends the solve (round-1 behaviour)")
-    ap.add_argument("--inflight", type=int, default=8,
+    ap.add_argument("--inflight", type=int, default=16,
                     help="launch lanes of the solver handle (mpcb_set_inflight): a batch is cut into that many chunks, chunk c of step k+1 "
                          "starts when chunk c of step k has finished, while the slowest instances of the other chunks still run (a launch "
                          "ends with its slowest instance and leaves most SIMDs idle before that); 1 = strictly one launch at a time")
@@ -397,8 +397,8 @@ def main():
     H = [bs] + [BatchSolver(cfg, device=local_rank, inflight=F) for _ in range(max(1, args.handles) - 1)]
     HN = len(H)
     R = F                                                   # ring of output-buffer sets per handle: solves closer than F apart may run concurrently
-    if HN * R > 16:
-        raise SystemExit("--handles x --inflight must be <= 16 (event slots of the gather ring)")
+    if HN * R > 32:
+        raise SystemExit("--handles x --inflight must be <= 32 (event slots of the gather ring)")
     D = []                                                  # per batch: the inputs, resident in HBM
     for (a0, a1, a2) in sets:
         D.append(dict(x0=bs.device_array((B, nx)).upload(a0), xs=bs.device_array((B, nx)).upload(a1), obs=bs.device_array(a2.shape).upload(a2)))

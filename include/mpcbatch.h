@@ -24,7 +24,7 @@
  *   - one handle = one device + one stream (+ optional launch lanes, mpcb_set_inflight); calls on one handle must be
  *     serialised by the caller (one host thread at a time).  A launch ends with its slowest instance, so throughput needs
  *     several launches in flight: mpcb_set_inflight(h, k) lets consecutive asynchronous mpcb_solve_device calls of ONE handle
- *     overlap (bench.py's default: one handle, eight lanes); distinct handles are independent as well.
+ *     overlap (bench.py's default: one handle, sixteen lanes); distinct handles are independent as well.
  *   - buffers of solves that are in flight at the same time (lanes, or several handles) must be distinct: in particular the
  *     status array, through which the two passes of a solve communicate.
  */
@@ -226,7 +226,7 @@ int mpcb_solve_device(mpcb_handle* h, int32_t B,
  * mpcb_sync, mpcb_event_*, or k = 1).  Work queued earlier on the handle (uploads, scene sampling) happens before a lane's
  * launch; every other entry point (mpcb_sync, mpcb_dev_download / _upload, mpcb_allgather, mpcb_stream_wait, mpcb_solve,
  * mpcb_closed_loop ...) waits for all lanes first and runs on the handle's own stream.  Results do not depend on k (bit-identical). */
-#define MPCB_INFLIGHT_MAX 8
+#define MPCB_INFLIGHT_MAX 16
 int mpcb_set_inflight(mpcb_handle* h, int32_t k);
 
 /* Closed loop on the device: `steps` receding-horizon iterations of  solve -> apply U_0 with the plant
@@ -326,7 +326,7 @@ int mpcb_stream_wait(mpcb_handle* h, mpcb_handle* other);
  * lanes, so later launches of h keep running ahead; mpcb_event_wait(h, other, slot) makes h's stream — and with it every later
  * lane launch of h — wait for other's mark `slot` (no-op if that slot was never recorded).  mpcb_stream_wait above is the coarse
  * form: everything queued so far on other. */
-#define MPCB_EVENT_SLOTS 16
+#define MPCB_EVENT_SLOTS 32
 int mpcb_event_record(mpcb_handle* h, int32_t slot);
 int mpcb_event_wait(mpcb_handle* h, const mpcb_handle* other, int32_t slot);
 

@@ -1,8 +1,17 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-mkdir -p gpurun_out
-timeout -k 10 1000 python -m pytest tests -m gpu -q > gpurun_out/r3_steer_pytest.log 2>&1
-tail -30 gpurun_out/r3_steer_pytest.log
-timeout -k 10 300 python tools/probe_variants.py 256 > gpurun_out/r03_steer_variants.txt 2>&1
-grep -c "status equal 1.0000" gpurun_out/r03_steer_variants.txt; grep -v "status equal 1.0000" gpurun_out/r03_steer_variants.txt | head
-timeout -k 10 300 python tools/fuzz_gpu_vs_oracle.py 100 31 > gpurun_out/r03_steer_fuzz.txt 2>&1; tail -3 gpurun_out/r03_steer_fuzz.txt
+mkdir -p gpurun_out; rm -f gpurun_out/r03_lanes4.txt
+run() { echo "== $1" >> gpurun_out/r03_lanes4.txt; python3 bench.py $1 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); c=d['config']; print(round(d['value']), d['ms_per_step'], c.get('solved_per_step'))" >> gpurun_out/r03_lanes4.txt; }
+run "--inflight 8"
+run "--inflight 10"
+run "--inflight 12"
+run "--inflight 16"
+run "--inflight 16 --steps 20 --warmup 5"
+run "--inflight 12 --steps 20 --warmup 5"
+run "--inflight 16 --config C3"
+run "--inflight 8 --config C3"
+run "--inflight 16 --config C4"
+run "--inflight 8 --config C4"
+run "--inflight 16 --config C5"
+cat gpurun_out/r03_lanes4.txt
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -q -k "lanes or handles or multi" 2>&1 | tail -3
