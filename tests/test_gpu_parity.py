@@ -29,8 +29,10 @@ def other_basin_allowance(n_both):
 
 def agree(gpu, ref, tol=TOL_Z, min_same_status=1.0):
     same = gpu["status"] == ref["status"]
-    assert same.mean() >= min_same_status, "status agreement %.4f" % same.mean()
     both = (gpu["status"] == 0) & (ref["status"] == 0)
+    print("agree(): status agreement %.4f (required %.2f), iteration counts equal on %.4f of the %d instances solved on both sides"
+          % (same.mean(), min_same_status, (gpu["iters"][both] == ref["iters"][both]).mean() if both.any() else 1.0, both.sum()))   # pytest -s: the measured margins
+    assert same.mean() >= min_same_status, "status agreement %.4f" % same.mean()
     assert both.sum() > 0
     err = np.abs(gpu["z"][both] - ref["z"][both]).max(axis=1)
     far = int((err > tol).sum())
@@ -108,15 +110,15 @@ def test_variants_horizons_modes(gpu_solver_factory, oracle_mod):
     x0, xs, obs = scenes.sample_c2(64, seed=6)
     for N in (1, 2, 20, 50, 63):
         cfg = default_config(N=N, n_obs=1)
-        agree(gpu_solver_factory(cfg).solve_batch(x0, xs, obs), oracle_mod.solve(cfg, x0, xs, obs), min_same_status=0.95)
+        agree(gpu_solver_factory(cfg).solve_batch(x0, xs, obs), oracle_mod.solve(cfg, x0, xs, obs), min_same_status=0.98)
     cfg = default_config(N=30, n_obs=1); cfg.obs_mode = _abi.OBS_DCBF
-    agree(gpu_solver_factory(cfg).solve_batch(x0, xs, obs), oracle_mod.solve(cfg, x0, xs, obs), min_same_status=0.95)
+    agree(gpu_solver_factory(cfg).solve_batch(x0, xs, obs), oracle_mod.solve(cfg, x0, xs, obs), min_same_status=0.98)
     cfg = default_config(N=30, n_obs=1); cfg.init_rollout = 0; cfg.mu_init = 0.1      # IPOPT-default-like settings
     g = gpu_solver_factory(cfg).solve_batch(G["S_x0"], G["S_xs"], G["S_obs"])
     assert g["status"][0] == 0 and np.abs(g["z"] - G["S_z"]).max() <= TOL_Z
     cfg = default_config(N=30, n_obs=8)
     ob = np.tile(np.array([[500.0, 3.5, 0, 0, 4.8, 1.8]]), (64, 8, 1)); ob[:, 0] = obs[:, 0]
-    agree(gpu_solver_factory(cfg).solve_batch(x0, xs, ob), oracle_mod.solve(cfg, x0, xs, ob), min_same_status=0.95)
+    agree(gpu_solver_factory(cfg).solve_batch(x0, xs, ob), oracle_mod.solve(cfg, x0, xs, ob), min_same_status=0.98)
 
 
 def test_edge_cases_on_device(gpu_solver_factory, yaml_horizon3):
@@ -454,7 +456,7 @@ def test_dynamic_bicycle_horizons_and_warm_start(gpu_solver_factory, oracle_mod)
     x0, xs, obs = scenes.sample_c4(32, seed=9, n_obs=1)
     for N in (1, 2, 50, 63):
         cfg = default_config(model=_abi.MODEL_DYN, N=N, n_obs=1)
-        agree(gpu_solver_factory(cfg).solve_batch(x0, xs, obs), oracle_mod.solve(cfg, x0, xs, obs), tol=TOL_Z_DYN, min_same_status=0.9)
+        agree(gpu_solver_factory(cfg).solve_batch(x0, xs, obs), oracle_mod.solve(cfg, x0, xs, obs), tol=TOL_Z_DYN, min_same_status=0.96)
     cfg = default_config(model=_abi.MODEL_DYN, N=40, n_obs=1)
     bs = gpu_solver_factory(cfg)
     cold = bs.solve_batch(x0, xs, obs)
@@ -465,7 +467,7 @@ def test_dynamic_bicycle_horizons_and_warm_start(gpu_solver_factory, oracle_mod)
     z0 = np.concatenate([np.concatenate([U[:, 1:], U[:, -1:]], 1).reshape(len(U), -1), np.concatenate([X[:, 1:], X[:, -1:]], 1).reshape(len(U), -1)], 1)
     x1 = X[:, 1].copy()
     g = bs.solve_batch(x1[ok], xs[ok], obs[ok], z0=z0[ok]); r = oracle_mod.solve(cfg, x1[ok], xs[ok], obs[ok], z0[ok])
-    agree(g, r, tol=TOL_Z_DYN, min_same_status=0.9)           # (a primal-only warm start does not save iterations on this model)
+    agree(g, r, tol=TOL_Z_DYN, min_same_status=0.96)           # (a primal-only warm start does not save iterations on this model)
 
 
 @pytest.mark.parametrize("model,n_obs", [(0, 0), (0, 2), (0, 3), (0, 5), (0, 8), (1, 0), (1, 2), (1, 5), (1, 8)])
@@ -488,10 +490,11 @@ def test_every_kernel_instantiation_full_outputs(gpu_solver_factory, oracle_mod,
         obs = obs[:, :n_obs]
     g = gpu_solver_factory(cfg).solve_batch(x0, xs, obs if n_obs else None, multipliers=True)
     r = oracle_mod.solve(cfg, x0, xs, obs if n_obs else None)
-    # Measured agreement (tools/probe_variants.py, 256 instances per variant): >= 99.6 % equal statuses, >= 97 % equal iteration counts.
+    # Measured agreement (this test, round 3, pytest -s): 100 % equal statuses on eight variants, 98.96 % (one instance) on one; >= 95.8 % equal
+    # iteration counts.  tools/probe_variants.py, 256 instances per variant: 100 % equal statuses, >= 98.8 % equal iteration counts.
     # The GPU-only wrong-code cases met so far showed as 78..95 % equal statuses and <= 92 % equal iteration counts.
-    both = agree(g, r, tol=tol, min_same_status=0.97)
-    assert (g["iters"][both] == r["iters"][both]).mean() >= 0.94
+    both = agree(g, r, tol=tol, min_same_status=0.975)
+    assert (g["iters"][both] == r["iters"][both]).mean() >= 0.95
     sc_g = np.maximum(1.0, np.abs(r["lam_g"][both]).max(axis=1, keepdims=True))
     assert (np.abs(g["lam_g"][both] - r["lam_g"][both]) / sc_g).max() <= 1e-4
     sc_x = np.maximum(1.0, np.abs(r["lam_x"][both]).max(axis=1, keepdims=True))
@@ -518,8 +521,8 @@ def test_general_gamma_cbf_rows(gpu_solver_factory, oracle_mod, n_obs, gamma):
     cfg = default_config(N=30, n_obs=n_obs); cfg.obs_mode = _abi.OBS_DCBF; cfg.gamma = gamma
     x0, xs, _, traj = scenes.sample_c3(96, N=30, dt=0.1, seed=300 + n_obs, n_obs=n_obs)
     g = gpu_solver_factory(cfg).solve_batch(x0, xs, traj, multipliers=True); r = oracle_mod.solve(cfg, x0, xs, traj)
-    both = agree(g, r, min_same_status=0.97)
-    assert (g["iters"][both] == r["iters"][both]).mean() >= 0.94
+    both = agree(g, r, min_same_status=0.975)
+    assert (g["iters"][both] == r["iters"][both]).mean() >= 0.95
     sc = np.maximum(1.0, np.abs(r["lam_g"][both]).max(axis=1, keepdims=True))
     assert (np.abs(g["lam_g"][both] - r["lam_g"][both]) / sc).max() <= 1e-4
     assert np.abs(g["obj"][both] / r["obj"][both] - 1).max() <= 1e-8
@@ -540,7 +543,7 @@ def test_rk4_shooting_rows_on_device(gpu_solver_factory, oracle_mod):
     x0, xs, obs = scenes.sample_c2(256, seed=91)
     bs = gpu_solver_factory(cfg)
     g = bs.solve_batch(x0, xs, obs, multipliers=True); r = oracle_mod.solve(cfg, x0, xs, obs)
-    both = agree(g, r, min_same_status=0.97)
+    both = agree(g, r, min_same_status=0.975)
     assert both.sum() >= 230 and (g["iters"] == r["iters"])[both].mean() >= 0.9
     for b in np.nonzero(g["status"] == 0)[0][:24]:
         c = kkt_check.certificate(kkt_check.KinNlp(30, 0.1, x0[b], xs[b], obs[b], integrator="rk4"), g["z"][b], g["lam_g"][b], g["lam_x"][b])
@@ -550,7 +553,7 @@ def test_rk4_shooting_rows_on_device(gpu_solver_factory, oracle_mod):
     assert 1e-3 < np.median(np.abs(g["z"] - e["z"])[bb].max(axis=1)) < 1.0              # another discretisation of the same manoeuvre
     c3 = default_config(N=30, n_obs=3); c3.integrator = _abi.INT_RK4
     y0, ys, _, traj = scenes.sample_c3(128, N=30, dt=0.1, seed=92)
-    agree(gpu_solver_factory(c3).solve_batch(y0, ys, traj), oracle_mod.solve(c3, y0, ys, traj), min_same_status=0.95)
+    agree(gpu_solver_factory(c3).solve_batch(y0, ys, traj), oracle_mod.solve(c3, y0, ys, traj), min_same_status=0.98)
     # closed loop: x_{t+1} is the RK4 step of the plant with the applied control
     cl = bs.closed_loop(x0[:32], xs[:32], obs[:32], steps=6)
     X, Uh = cl["x_hist"], cl["u_hist"]

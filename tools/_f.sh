@@ -1,17 +1,6 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-mkdir -p gpurun_out; rm -f gpurun_out/r03_lanes4.txt
-run() { echo "== $1" >> gpurun_out/r03_lanes4.txt; python3 bench.py $1 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); c=d['config']; print(round(d['value']), d['ms_per_step'], c.get('solved_per_step'))" >> gpurun_out/r03_lanes4.txt; }
-run "--inflight 8"
-run "--inflight 10"
-run "--inflight 12"
-run "--inflight 16"
-run "--inflight 16 --steps 20 --warmup 5"
-run "--inflight 12 --steps 20 --warmup 5"
-run "--inflight 16 --config C3"
-run "--inflight 8 --config C3"
-run "--inflight 16 --config C4"
-run "--inflight 8 --config C4"
-run "--inflight 16 --config C5"
-cat gpurun_out/r03_lanes4.txt
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -q -k "lanes or handles or multi" 2>&1 | tail -3
+mkdir -p gpurun_out
+timeout -k 10 1000 python -m pytest tests/test_gpu_parity.py -q > gpurun_out/r3_tight.log 2>&1
+tail -8 gpurun_out/r3_tight.log
+for s in 31 32 33; do timeout -k 10 250 python tools/fuzz_gpu_vs_oracle.py 100 $s > gpurun_out/r03_fuzz_$s.txt 2>&1; tail -1 gpurun_out/r03_fuzz_$s.txt; grep -o "one side only [0-9]*" gpurun_out/r03_fuzz_$s.txt | sort | uniq -c; done

@@ -64,8 +64,8 @@ def one_case(rng, c):
     # what must agree: WHICH instances are solved (the way a failing instance fails — iteration cap, line search, numerics —
     # may differ between two roundings of the same algorithm), allowing one borderline instance per batch
     flips = int(((g["status"] == 0) != (r["status"] == 0)).sum())
-    ok = flips <= max(1, B // 10) and far <= max(1, B // 20) and bool(np.all(np.isfinite(g["z"])))
-    return ok, desc + " -> status agreement %.2f, solved %d/%d, L-inf(z) %.2e, other basin %d%s" % (same, int(both.sum()), B, err, far, "" if ok else "  <-- MISMATCH")
+    ok = flips <= max(1, B // 16) and far <= max(1, B // 32) and bool(np.all(np.isfinite(g["z"])))     # (round 2: B // 10 and B // 20; measured over 3 x 100 cases since: at most 3 of 64 flips, 1 other basin)
+    return ok, desc + " -> status agreement %.2f, solved %d/%d, solved on one side only %d, L-inf(z) %.2e, other basin %d%s" % (same, int(both.sum()), B, flips, err, far, "" if ok else "  <-- MISMATCH")
 
 
 def run(cases=60, seed=0, verbose=True):
