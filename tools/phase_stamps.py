@@ -6,7 +6,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 out = os.path.join(ROOT, "mpc_motion_planning_amd", "lib", "libmpcbatch_stamps.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-fno-gpu-rdc",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-fno-gpu-rdc", "-mllvm", "-amdgpu-opt-vgpr-liverange=false",
                        "-DMPCB_STAMPS"] + [a for a in sys.argv[1:] if a.startswith("-D")] + ["-o", out, os.path.join(ROOT, "mpc_motion_planning_amd", "csrc", "mpcb_api.hip")],
                       stderr=subprocess.DEVNULL)
 import mpc_motion_planning_amd._lib as _lib
