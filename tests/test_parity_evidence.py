@@ -48,8 +48,10 @@ def _pool():
 
 
 def _sample(conf, B, seed):
-    if conf == "C2":
+    if conf in ("C2", "C2rk4"):
         cfg = default_config(N=30, n_obs=1); x0, xs, obs = scenes.sample_c2(B, seed=seed)
+        if conf == "C2rk4":
+            cfg.integrator = _abi.INT_RK4                      # Runge-Kutta shooting rows (BASELINE.json's north_star; opt-in)
     elif conf == "C3":
         cfg = default_config(N=30, n_obs=3); x0, xs, _, obs = scenes.sample_c3(B, N=30, dt=0.1, seed=seed)
     else:
@@ -191,14 +193,15 @@ def _slsqp_one(args):
     if conf == "C4":
         nlp = kkt_check.DynNlp(40, 0.1, x0, xs, ob); rhs0 = lambda x: nlp.rhs(x[None, :], np.zeros((1, 2)))[0]      # noqa: E731
     else:
-        nlp = kkt_check.KinNlp(30, 0.1, x0, xs, ob); rhs0 = lambda x: np.array([x[3] * np.cos(x[2]), x[3] * np.sin(x[2]), 0.0, 0.0])   # noqa: E731
+        nlp = kkt_check.KinNlp(30, 0.1, x0, xs, ob, integrator="rk4" if conf == "C2rk4" else "euler")
+        rhs0 = lambda x: np.array([x[3] * np.cos(x[2]), x[3] * np.sin(x[2]), 0.0, 0.0])   # noqa: E731
     z, f, s = sc.solve_slsqp(nlp, sc.cold_start(nlp, 0.1, rhs0), maxiter=600)
     g = nlp.g(z)
     viol = float(np.maximum(0, np.maximum(nlp.lbg - g, g - nlp.ubg)).max())
     return float(np.abs(z - z_dev).max()), float(f / f_dev - 1.0), int(s.status), viol
 
 
-@pytest.mark.parametrize("conf,count", [("C2", 48), ("C3", 48), ("C4", 24)])
+@pytest.mark.parametrize("conf,count", [("C2", 48), ("C3", 48), ("C4", 24), ("C2rk4", 24)])
 def test_same_basin_fraction_against_slsqp(gpu_solver_factory, evidence, conf, count):
     cfg, x0, xs, obs = _sample(conf, 4 * count, seed=123)
     r = gpu_solver_factory(cfg).solve_batch(x0, xs, obs)
