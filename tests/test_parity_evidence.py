@@ -185,6 +185,49 @@ def test_unsolved_c3_instances_audited_by_an_independent_solver(gpu_solver_facto
     assert (r["status"] == 0).mean() >= 0.95 and len(left) >= 1
 
 
+def _audit_one_dyn(args):
+    sys.path.insert(0, ROOT)
+    from oracle import kkt_check, scipy_crosscheck as sc
+    x0, xs, ob, z_dev = args
+    nlp = kkt_check.DynNlp(40, 0.1, x0, xs, ob)
+    N = nlp.N
+    starts = [z_dev]
+    for ylane in (-0.5, 1.75, 4.5):                           # between / beside the obstacle rows of the C4 scenes, inside the y box [-1, 5]
+        for brake in (False, True):
+            X = np.zeros((N + 1, 6)); X[0] = x0; U = np.zeros((N, 2))
+            for k in range(N):
+                a = -3.0 if (brake and X[k, 3] > 1.0) else 0.0
+                U[k, 1] = a
+                X[k + 1] = X[k] + 0.1 * np.array([X[k, 3] * np.cos(X[k, 2]), X[k, 3] * np.sin(X[k, 2]), 0.0, a, 0.0, 0.0])
+            X[1:, 1] = x0[1] + (ylane - x0[1]) * np.minimum(1.0, np.arange(1, N + 1) / 15.0)
+            starts.append(np.concatenate([U.reshape(-1), X.reshape(-1)]))
+    best = (np.inf, np.inf)
+    for z0 in starts:
+        S, viol, _ = sc.min_violation_slsqp(nlp, z0, maxiter=200)
+        if viol < best[1]:
+            best = (S, viol)
+        if best[1] <= 1e-8:
+            break
+    return best
+
+
+def test_unsolved_c4_instances_audited_by_an_independent_solver(gpu_solver_factory, evidence):
+    """The audit on C4 (dynamic bicycle, N = 40, three static obstacles; 0.8 % of the bench workload ends unsolved), reference row form
+    sqrt(h) >= 1 (oracle/kkt_check.DynNlp): what the shipped configuration leaves unsolved in 1024 scenes."""
+    cfg, x0, xs, obs = _sample("C4", 1024, seed=305)
+    r = gpu_solver_factory(cfg).solve_batch(x0, xs, obs)
+    left = np.nonzero((r["status"] != 0) & (r["status"] != _abi.ST_INFEASIBLE_X0))[0][:24]
+    with _pool() as p:
+        res = p.map(_audit_one_dyn, [(x0[i], xs[i], obs[i], r["z"][i]) for i in left], chunksize=1) if len(left) else []
+    viol = np.array([v for _, v in res]) if len(res) else np.zeros(0)
+    evidence["unsolved_audit_C4"] = {"instances": len(x0), "solved": int((r["status"] == 0).sum()), "unsolved": int((r["status"] != 0).sum()),
+                                     "audited": int(len(left)), "feasible_point_found_by_slsqp": int((viol <= 1e-8).sum()),
+                                     "status_histogram": np.bincount(r["status"], minlength=9).tolist(),
+                                     "method": "as infeasible_audit_C2 on kkt_check.DynNlp, up to 7 starts (device iterate, three lateral positions x braked / unbraked)"}
+    print(evidence["unsolved_audit_C4"])
+    assert (r["status"] == 0).mean() >= 0.97
+
+
 # ---------------------------------------------------------------------------------------------------------------- (c)
 def _slsqp_one(args):
     sys.path.insert(0, ROOT)
